@@ -1,0 +1,638 @@
+// mc.hip -- GPU marching cubes for gfx950, replacing the reference's
+// `computeMarchingCubes <dist> <obj> -i iso` step (reference:
+// demo/demo.py:355-369; algorithm: SURVEY.md Appendix B).
+//
+// HBM-bound scan/compaction.  Pipeline (all on the caller's stream):
+//   mc_classify   per grid point: voxel sub-table id + 3 edge-slot flags
+//                 -> info[P] (u16), per-block counters
+//   mc_scan       one workgroup: exclusive scan of the block counters,
+//                 per-layer centre offsets, totals
+//   mc_vertices   block scan of the slot flags -> vbase[P] (u32) and the edge
+//                 vertices, already in the reference's key order
+//   mc_triangles  block scan of triangle/centre counts -> triangles with final
+//                 indices (smallest first) + centre vertices
+//   tri_sort_*    LSD radix sort (8-bit digits) -> lexicographic order
+// Algorithmic bytes: 4 B/grid point + 24 B/vertex + 12 B/triangle.
+// Compile with -ffp-contract=off: App. B specifies separately rounded
+// products; the arithmetic intrinsics below make that explicit as well.
+#include <float.h>
+
+#include "common.h"
+
+#define DISN_MC_QUAL __device__
+#include "../../include/disn_mc_tables.h"
+
+namespace {
+
+constexpr int BLK = 256;
+constexpr int ITEMS = 4;
+constexpr int TILE = BLK * ITEMS;
+constexpr unsigned NOSUB = 0x3ffu;
+
+struct Dims {
+  int nx, ny, nz;
+  unsigned sxy;   // nx*ny
+  unsigned P;     // nx*ny*nz
+  int own0, own1;
+  int z_offset;
+  float iso;
+};
+
+__device__ __forceinline__ float cval(const float* __restrict__ sdf, unsigned p, float iso) {
+  float d = __fsub_rn(sdf[p], iso);  // B.1
+  return d == 0.0f ? FLT_EPSILON : d;
+}
+
+// B.3 faceTest
+__device__ int face_test(int f, const float* c) {
+  const unsigned char* fv = DISN_MC_FACE[(f < 0 ? -f : f) - 1];
+  float A = c[fv[0]], B = c[fv[1]], C = c[fv[2]], D = c[fv[3]];
+  float ac = __fmul_rn(A, C), bd = __fmul_rn(B, D);
+  return ((ac > bd) == (f > 0)) == (A > 0.0f);
+}
+
+// B.3 interiorTest
+__device__ int interior_test(int s, const float* c) {
+  float d10 = __fsub_rn(c[1], c[0]), d67 = __fsub_rn(c[6], c[7]);
+  float d54 = __fsub_rn(c[5], c[4]), d23 = __fsub_rn(c[2], c[3]);
+  float a = __fsub_rn(__fmul_rn(d10, d67), __fmul_rn(d54, d23));
+  float b = __fsub_rn(__fadd_rn(__fsub_rn(__fmul_rn(c[0], d67), __fmul_rn(c[4], d23)), __fmul_rn(d10, c[7])),
+                      __fmul_rn(d54, c[3]));
+  double t = __ddiv_rn(-(double)b, __dadd_rn((double)a, (double)a));
+  if (t < 0.0 || t > 1.0) return s > 0;
+  double At = __dadd_rn((double)c[0], __dmul_rn((double)d10, t));
+  double Bt = __dadd_rn((double)c[4], __dmul_rn((double)d54, t));
+  double Ct = __dadd_rn((double)c[7], __dmul_rn((double)d67, t));
+  double Dt = __dadd_rn((double)c[3], __dmul_rn((double)d23, t));
+  int test = (At >= 0) | ((Bt >= 0) << 1) | ((Ct >= 0) << 2) | ((Dt >= 0) << 3);
+  switch (test) {
+    case 5: return (s > 0) ^ (__dmul_rn(Bt, Dt) <= __dmul_rn(At, Ct));
+    case 10: return (s > 0) ^ (__dmul_rn(At, Ct) < __dmul_rn(Bt, Dt));
+    case 7: case 11: case 13: case 14: case 15: return s < 0;
+    default: return s > 0;
+  }
+}
+
+// B.2 + B.3: sub-table id, NOSUB when the voxel emits nothing
+__device__ unsigned classify(const float* c) {
+  int code = 0;
+#pragma unroll
+  for (int v = 0; v < 8; ++v) code |= (c[v] > 0.0f) << v;
+  if (code == 0 || code == 255) return NOSUB;
+  int cs = DISN_MC_CASE[code];
+  if (cs == 0) return NOSUB;
+  const signed char* ft = &DISN_MC_FACE_TESTS[7 * code];
+  int n = ft[0], amb = 0;
+  for (int t = 1; t <= n; ++t) amb |= face_test(ft[t], c) << (t - 1);
+  int it = DISN_MC_INTERIOR_TEST[code];
+  if (it) amb |= interior_test(it, c) << n;
+  int sub = DISN_MC_AMBIGUITY[64 * cs + amb];
+  if (sub < 0) return NOSUB;
+  return DISN_MC_SUB_START[code] + sub;
+}
+
+__device__ void load_corners(const float* __restrict__ sdf, const Dims& d, unsigned p, float* c) {
+  c[0] = cval(sdf, p, d.iso);
+  c[1] = cval(sdf, p + 1, d.iso);
+  c[2] = cval(sdf, p + 1 + d.nx, d.iso);
+  c[3] = cval(sdf, p + d.nx, d.iso);
+  c[4] = cval(sdf, p + d.sxy, d.iso);
+  c[5] = cval(sdf, p + d.sxy + 1, d.iso);
+  c[6] = cval(sdf, p + d.sxy + 1 + d.nx, d.iso);
+  c[7] = cval(sdf, p + d.sxy + d.nx, d.iso);
+}
+
+// rare path of B.4/B.9: is voxel (i,j,k) inside the grid and active?
+__device__ bool voxel_active(const float* __restrict__ sdf, const Dims& d, int i, int j, int k) {
+  if (i < 0 || j < 0 || k < 0 || i >= d.nx - 1 || j >= d.ny - 1 || k >= d.nz - 1) return false;
+  float c[8];
+  load_corners(sdf, d, (unsigned)k * d.sxy + (unsigned)j * d.nx + i, c);
+  return classify(c) != NOSUB;
+}
+
+// same-sign "crossed by underflow" edge: it owns a vertex only if one of the
+// voxels around it is active (B.9)
+__device__ bool underflow_edge_live(const float* __restrict__ sdf, const Dims& d, int i, int j, int k, int dir) {
+  for (int a = -1; a <= 0; ++a)
+    for (int b = -1; b <= 0; ++b) {
+      bool live = dir == 0 ? voxel_active(sdf, d, i, j + a, k + b)
+                : dir == 1 ? voxel_active(sdf, d, i + a, j, k + b)
+                           : voxel_active(sdf, d, i + a, j + b, k);
+      if (live) return true;
+    }
+  return false;
+}
+
+// block-wide exclusive scan of one unsigned per thread (BLK = 256 = 4 waves);
+// returns the exclusive prefix, *total receives the block sum
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* lds /*[4]*/, unsigned* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned inc = wave_incl_scan(v, lane);
+  __syncthreads();  // protect lds reuse between consecutive calls
+  if (lane == 63) lds[w] = inc;
+  __syncthreads();
+  unsigned pre = 0, tot = 0;
+#pragma unroll
+  for (int q = 0; q < BLK / 64; ++q) {
+    unsigned s = lds[q];
+    if (q < w) pre += s;
+    tot += s;
+  }
+  *total = tot;
+  return pre + inc - v;
+}
+
+// counters per block: 0 E_all, 1 T_own, 2 C_own, 3 E_low, 4 E_own
+constexpr int NCNT = 5;
+
+__global__ __launch_bounds__(BLK) void mc_classify(const float* __restrict__ sdf, Dims d, uint16_t* __restrict__ info,
+                                                    unsigned* __restrict__ bsum, unsigned* __restrict__ layer_centre) {
+  __shared__ unsigned red[BLK / 64][NCNT];
+  unsigned cnt[NCNT] = {0, 0, 0, 0, 0};
+  const unsigned base = blockIdx.x * TILE;
+  for (int r = 0; r < ITEMS; ++r) {
+    unsigned p = base + r * BLK + threadIdx.x;
+    if (p >= d.P) break;
+    int i = p % d.nx;
+    unsigned q = p / d.nx;
+    int j = q % d.ny;
+    int k = q / d.ny;
+    const bool hx = i < d.nx - 1, hy = j < d.ny - 1, hz = k < d.nz - 1;
+    float c[8];
+    c[0] = cval(sdf, p, d.iso);
+    c[1] = hx ? cval(sdf, p + 1, d.iso) : 1.0f;
+    c[3] = hy ? cval(sdf, p + d.nx, d.iso) : 1.0f;
+    c[4] = hz ? cval(sdf, p + d.sxy, d.iso) : 1.0f;
+    unsigned flags = 0;
+    const bool has[3] = {hx, hy, hz};
+    const float cn[3] = {c[1], c[3], c[4]};
+#pragma unroll
+    for (int dir = 0; dir < 3; ++dir) {
+      if (!has[dir]) continue;
+      if (__fmul_rn(c[0], cn[dir]) <= 0.0f) {  // B.4
+        bool live = ((c[0] > 0.0f) != (cn[dir] > 0.0f)) || underflow_edge_live(sdf, d, i, j, k, dir);
+        if (live) flags |= 1u << dir;
+      }
+    }
+    unsigned sub = NOSUB;
+    if (hx && hy && hz) {
+      c[2] = cval(sdf, p + 1 + d.nx, d.iso);
+      c[5] = cval(sdf, p + d.sxy + 1, d.iso);
+      c[6] = cval(sdf, p + d.sxy + 1 + d.nx, d.iso);
+      c[7] = cval(sdf, p + d.sxy + d.nx, d.iso);
+      sub = classify(c);
+    }
+    info[p] = (uint16_t)(sub | (flags << 10));
+    const unsigned ne = __popc(flags);
+    cnt[0] += ne;
+    if (k < d.own0) cnt[3] += ne;
+    if (k >= d.own0 && k < d.own1) {
+      cnt[4] += ne;
+      if (sub != NOSUB) {
+        const unsigned char* s = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub]];
+        cnt[1] += s[0] / 3;
+        if (s[1]) {
+          cnt[2] += 1;
+          atomicAdd(&layer_centre[k], 1u);
+        }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int n = 0; n < NCNT; ++n) {
+    unsigned v = cnt[n];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) red[w][n] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NCNT) {
+    unsigned v = 0;
+    for (int q = 0; q < BLK / 64; ++q) v += red[q][threadIdx.x];
+    bsum[(size_t)blockIdx.x * NCNT + threadIdx.x] = v;
+  }
+}
+
+// one workgroup of 1024 threads.  boff[b][0..2] = exclusive prefix of
+// (E_all, T_own, C_own); totals[0..4] = sums of the five counters (u64);
+// layer[k] (in: centres of layer k) -> layer_asc[k] = centres in layers < k.
+__global__ __launch_bounds__(1024) void mc_scan(const unsigned* __restrict__ bsum, unsigned nb, unsigned* __restrict__ boff,
+                                                 unsigned long long* __restrict__ totals,
+                                                 const unsigned* __restrict__ layer_centre, unsigned* __restrict__ layer_asc,
+                                                 int nz) {
+  __shared__ unsigned long long part[1024];
+  const unsigned chunk = (nb + 1023) / 1024;
+  const unsigned b0 = threadIdx.x * chunk, b1 = min(nb, b0 + chunk);
+  for (int n = 0; n < NCNT; ++n) {
+    unsigned long long s = 0;
+    for (unsigned b = b0; b < b1; ++b) s += bsum[(size_t)b * NCNT + n];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int o = 1; o < 1024; o <<= 1) {
+      unsigned long long t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (threadIdx.x == 1023) totals[n] = part[1023];
+    if (n < 3) {
+      unsigned long long run = part[threadIdx.x] - s;
+      for (unsigned b = b0; b < b1; ++b) {
+        boff[(size_t)b * 3 + n] = (unsigned)run;
+        run += bsum[(size_t)b * NCNT + n];
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (int k = 0; k < nz; ++k) {
+      layer_asc[k] = run;
+      run += layer_centre[k];
+    }
+    layer_asc[nz] = run;
+  }
+}
+
+struct EmitArgs {
+  double lo[3], h[3];
+  unsigned long long centre_base, edge_base;
+  unsigned e_low;      // slots in planes below own0
+  unsigned c_own;      // centre vertices owned
+  double* verts;       // local output: [c_own centres][e_own edges]
+  long long* keys;     // or null
+  int* tris;
+};
+
+__device__ __forceinline__ void edge_position(const float* __restrict__ sdf, const Dims& d, const EmitArgs& a, int i, int j,
+                                              int k, unsigned p, int dir, double* pos) {
+  const unsigned stride = dir == 0 ? 1u : dir == 1 ? (unsigned)d.nx : d.sxy;
+  float ca = cval(sdf, p, d.iso), cb = cval(sdf, p + stride, d.iso);
+  pos[0] = __dadd_rn(a.lo[0], __dmul_rn((double)i, a.h[0]));
+  pos[1] = __dadd_rn(a.lo[1], __dmul_rn((double)j, a.h[1]));
+  pos[2] = __dadd_rn(a.lo[2], __dmul_rn((double)(k + d.z_offset), a.h[2]));
+  float diff = __fsub_rn(ca, cb);
+  pos[dir] = __dadd_rn(pos[dir], __ddiv_rn(__dmul_rn((double)ca, a.h[dir]), (double)diff));  // B.4
+}
+
+__global__ __launch_bounds__(BLK) void mc_vertices(const float* __restrict__ sdf, Dims d, const uint16_t* __restrict__ info,
+                                                    const unsigned* __restrict__ boff, unsigned* __restrict__ vbase,
+                                                    EmitArgs a) {
+  __shared__ unsigned lds[BLK / 64];
+  const unsigned base = blockIdx.x * TILE;
+  unsigned carry = boff[(size_t)blockIdx.x * 3 + 0];
+  for (int r = 0; r < ITEMS; ++r) {
+    unsigned p = base + r * BLK + threadIdx.x;
+    unsigned flags = p < d.P ? (unsigned)(info[p] >> 10) & 7u : 0u;
+    unsigned ne = __popc(flags), tot;
+    unsigned vb = carry + block_excl_scan(ne, lds, &tot);
+    carry += tot;
+    if (p >= d.P) continue;
+    vbase[p] = vb;
+    if (!flags) continue;
+    int i = p % d.nx;
+    unsigned q = p / d.nx;
+    int j = q % d.ny;
+    int k = q / d.ny;
+    if (k < d.own0 || k >= d.own1) continue;
+    unsigned long long out = (unsigned long long)a.c_own + (vb - a.e_low);
+#pragma unroll
+    for (int dir = 0; dir < 3; ++dir) {
+      if (!(flags >> dir & 1)) continue;
+      double pos[3];
+      edge_position(sdf, d, a, i, j, k, p, dir, pos);
+      a.verts[3 * out + 0] = pos[0];
+      a.verts[3 * out + 1] = pos[1];
+      a.verts[3 * out + 2] = pos[2];
+      if (a.keys)
+        a.keys[out] = 3ll * (((long long)(k + d.z_offset) * d.ny + j) * d.nx + i) + dir;
+      ++out;
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLK) void mc_triangles(const float* __restrict__ sdf, Dims d, const uint16_t* __restrict__ info,
+                                                     const unsigned* __restrict__ boff, const unsigned* __restrict__ vbase,
+                                                     const unsigned* __restrict__ layer_asc, EmitArgs a) {
+  __shared__ unsigned lds[BLK / 64];
+  const unsigned base = blockIdx.x * TILE;
+  unsigned carry_t = boff[(size_t)blockIdx.x * 3 + 1];
+  unsigned carry_c = boff[(size_t)blockIdx.x * 3 + 2];
+  for (int r = 0; r < ITEMS; ++r) {
+    unsigned p = base + r * BLK + threadIdx.x;
+    unsigned sub = NOSUB;
+    int i = 0, j = 0, k = 0;
+    if (p < d.P) {
+      i = p % d.nx;
+      unsigned q = p / d.nx;
+      j = q % d.ny;
+      k = q / d.ny;
+      if (k >= d.own0 && k < d.own1) sub = info[p] & NOSUB;
+    }
+    const unsigned char* s = nullptr;
+    unsigned nt = 0, nc = 0;
+    if (sub != NOSUB) {
+      s = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub]];
+      nt = s[0] / 3;
+      nc = s[1];
+    }
+    unsigned tot;
+    unsigned ex = block_excl_scan(nt | (nc << 16), lds, &tot);
+    unsigned tb = carry_t + (ex & 0xffffu), cb = carry_c + (ex >> 16);
+    carry_t += tot & 0xffffu;
+    carry_c += tot >> 16;
+    if (sub == NOSUB) continue;
+    // index of each of the 12 edges' vertices (only those referenced are read)
+    long long centre_idx = -1;
+    if (nc) {
+      // B.5/B.6: centres ordered by descending k, then ascending (j,i)
+      unsigned in_layer = cb - layer_asc[k];
+      unsigned desc = (a.c_own - layer_asc[k + 1]) + in_layer;
+      centre_idx = (long long)a.centre_base + desc;
+      double acc[3] = {0, 0, 0};
+      int n = 0;
+      for (int e = 0; e < 12; ++e) {
+        int ca = DISN_MC_EDGE[e][0], dir = DISN_MC_EDGE[e][2];
+        int di = DISN_MC_CORNER[ca][0], dj = DISN_MC_CORNER[ca][1], dk = DISN_MC_CORNER[ca][2];
+        unsigned pa = p + di + dj * d.nx + dk * d.sxy;
+        if (!((info[pa] >> 10) >> dir & 1)) continue;
+        double pos[3];
+        edge_position(sdf, d, a, i + di, j + dj, k + dk, pa, dir, pos);
+        acc[0] = __dadd_rn(acc[0], pos[0]);
+        acc[1] = __dadd_rn(acc[1], pos[1]);
+        acc[2] = __dadd_rn(acc[2], pos[2]);
+        ++n;
+      }
+      a.verts[3 * (size_t)desc + 0] = __ddiv_rn(acc[0], (double)n);
+      a.verts[3 * (size_t)desc + 1] = __ddiv_rn(acc[1], (double)n);
+      a.verts[3 * (size_t)desc + 2] = __ddiv_rn(acc[2], (double)n);
+      if (a.keys) a.keys[desc] = -(long long)(k + d.z_offset) * d.sxy + (long long)j * d.nx + i - 1;
+    }
+    for (unsigned t = 0; t < nt; ++t) {
+      int v[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        int e = s[2 + 3 * t + q];
+        if (e == 12) {
+          v[q] = (int)centre_idx;
+        } else {
+          int ca = DISN_MC_EDGE[e][0], dir = DISN_MC_EDGE[e][2];
+          unsigned pa = p + DISN_MC_CORNER[ca][0] + DISN_MC_CORNER[ca][1] * d.nx + DISN_MC_CORNER[ca][2] * d.sxy;
+          unsigned fl = (unsigned)(info[pa] >> 10);
+          v[q] = (int)(a.edge_base + (vbase[pa] - a.e_low) + __popc(fl & ((1u << dir) - 1u)));
+        }
+      }
+      int m = 0;  // B.6: rotate, smallest index first
+      if (v[1] < v[m]) m = 1;
+      if (v[2] < v[m]) m = 2;
+      int r0 = v[m], r1 = v[m == 2 ? 0 : m + 1], r2 = v[m == 0 ? 2 : m - 1];
+      int* o = a.tris + 3 * (size_t)(tb + t);
+      o[0] = r0;
+      o[1] = r1;
+      o[2] = r2;
+    }
+  }
+}
+
+// ---- LSD radix sort of (a,b,c) int32 triples ------------------------------
+constexpr int SORT_ITEMS = 8;
+constexpr int SORT_TILE = BLK * SORT_ITEMS;
+
+__global__ __launch_bounds__(BLK) void tri_sort_hist(const int* __restrict__ tris, unsigned long long n, int comp, int shift,
+                                                      unsigned* __restrict__ hist, unsigned nb) {
+  __shared__ unsigned h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned long long base = (unsigned long long)blockIdx.x * SORT_TILE;
+  for (int r = 0; r < SORT_ITEMS; ++r) {
+    unsigned long long t = base + r * BLK + threadIdx.x;
+    if (t < n) atomicAdd(&h[((unsigned)tris[3 * t + comp] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];  // digit-major
+}
+
+// exclusive scan of hist[256*nb] in place (one workgroup)
+__global__ __launch_bounds__(1024) void tri_sort_scan(unsigned* __restrict__ hist, unsigned n) {
+  __shared__ unsigned part[1024];
+  const unsigned chunk = (n + 1023) / 1024;
+  const unsigned b0 = min(n, threadIdx.x * chunk), b1 = min(n, b0 + chunk);
+  unsigned s = 0;
+  for (unsigned b = b0; b < b1; ++b) s += hist[b];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    unsigned t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  unsigned run = part[threadIdx.x] - s;
+  for (unsigned b = b0; b < b1; ++b) {
+    unsigned v = hist[b];
+    hist[b] = run;
+    run += v;
+  }
+}
+
+__global__ __launch_bounds__(BLK) void tri_sort_scatter(const int* __restrict__ in, int* __restrict__ out,
+                                                         unsigned long long n, int comp, int shift,
+                                                         const unsigned* __restrict__ hist, unsigned nb) {
+  __shared__ unsigned basecnt[256];
+  __shared__ unsigned wcnt[BLK / 64][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  basecnt[threadIdx.x] = hist[(size_t)threadIdx.x * nb + blockIdx.x];
+  unsigned long long base = (unsigned long long)blockIdx.x * SORT_TILE;
+  for (int r = 0; r < SORT_ITEMS; ++r) {
+#pragma unroll
+    for (int q = 0; q < BLK / 64; ++q) wcnt[q][threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long t = base + r * BLK + threadIdx.x;
+    const bool valid = t < n;
+    int k0 = 0, k1 = 0, k2 = 0;
+    unsigned dg = 0;
+    if (valid) {
+      k0 = in[3 * t];
+      k1 = in[3 * t + 1];
+      k2 = in[3 * t + 2];
+      dg = ((unsigned)(comp == 0 ? k0 : comp == 1 ? k1 : k2) >> shift) & 255u;
+    }
+    // lanes of this wave holding the same digit
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      unsigned long long m = __ballot((dg >> b) & 1u);
+      peers &= ((dg >> b) & 1u) ? m : ~m;
+    }
+    unsigned rank = __popcll(peers & ((1ull << lane) - 1ull));
+    if (valid && rank == 0) wcnt[w][dg] = __popcll(peers);
+    __syncthreads();
+    if (valid) {
+      unsigned off = basecnt[dg] + rank;
+      for (int q = 0; q < w; ++q) off += wcnt[q][dg];
+      out[3 * (size_t)off] = k0;
+      out[3 * (size_t)off + 1] = k1;
+      out[3 * (size_t)off + 2] = k2;
+    }
+    __syncthreads();
+    unsigned add = 0;
+#pragma unroll
+    for (int q = 0; q < BLK / 64; ++q) add += wcnt[q][threadIdx.x];
+    basecnt[threadIdx.x] += add;
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+struct McState {
+  DevBuf info, vbase, bsum, boff, layer, layer_asc, totals, sort_tmp, sort_hist;
+  bool counted = false;
+  const float* sdf = nullptr;
+  Dims d{};
+  int nz_global = 0;
+  unsigned nb = 0;
+  unsigned long long tot[NCNT] = {0, 0, 0, 0, 0};
+};
+
+void disn_mc_state_free(DisnCtx* ctx) {
+  if (!ctx->mc) return;
+  McState* m = ctx->mc;
+  DevBuf* all[] = {&m->info, &m->vbase, &m->bsum, &m->boff, &m->layer, &m->layer_asc, &m->totals, &m->sort_tmp, &m->sort_hist};
+  for (DevBuf* b : all) disn_release(*b);
+  delete m;
+  ctx->mc = nullptr;
+}
+
+static McState* mc_state(DisnCtx* ctx) {
+  if (!ctx->mc) ctx->mc = new McState();
+  return ctx->mc;
+}
+
+extern "C" int disn_mc_count(DisnCtx* ctx, const float* sdf, const DisnMcGrid* g, float iso, uint64_t counts[3],
+                             void* stream_) {
+  if (!ctx) return DISN_E_ARG;
+  if (!sdf || !g || !counts) return disn_fail(ctx, DISN_E_ARG, "disn_mc_count: null argument");
+  if (g->nx < 2 || g->ny < 2 || g->nz < 2) return disn_fail(ctx, DISN_E_ARG, "disn_mc_count: grid needs >= 2 points per axis");
+  if (g->own0 < 0 || g->own1 > g->nz || g->own0 >= g->own1)
+    return disn_fail(ctx, DISN_E_ARG, "disn_mc_count: bad owned plane range [%d,%d) of %d", g->own0, g->own1, g->nz);
+  if (g->z_offset < 0 || g->z_offset + g->nz > g->nz_global)
+    return disn_fail(ctx, DISN_E_ARG, "disn_mc_count: slab [%d,%d) outside global grid of %d planes", g->z_offset,
+                     g->z_offset + g->nz, g->nz_global);
+  const uint64_t P64 = (uint64_t)g->nx * g->ny * g->nz;
+  if (P64 * 3 >= (1ull << 32)) return disn_fail(ctx, DISN_E_ARG, "disn_mc_count: grid too large for 32-bit slot indices");
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  McState* m = mc_state(ctx);
+  m->counted = false;
+  Dims d;
+  d.nx = g->nx; d.ny = g->ny; d.nz = g->nz;
+  d.sxy = (unsigned)g->nx * g->ny;
+  d.P = (unsigned)P64;
+  d.own0 = g->own0; d.own1 = g->own1;
+  d.z_offset = g->z_offset;
+  d.iso = iso;
+  const unsigned nb = (unsigned)((P64 + TILE - 1) / TILE);
+  DISN_TRY(disn_ensure(ctx, m->info, P64 * sizeof(uint16_t)));
+  DISN_TRY(disn_ensure(ctx, m->bsum, (size_t)nb * NCNT * sizeof(unsigned)));
+  DISN_TRY(disn_ensure(ctx, m->boff, (size_t)nb * 3 * sizeof(unsigned)));
+  DISN_TRY(disn_ensure(ctx, m->layer, (size_t)(g->nz + 1) * sizeof(unsigned)));
+  DISN_TRY(disn_ensure(ctx, m->layer_asc, (size_t)(g->nz + 2) * sizeof(unsigned)));
+  DISN_TRY(disn_ensure(ctx, m->totals, NCNT * sizeof(unsigned long long)));
+  DISN_HIP(ctx, hipMemsetAsync(m->layer.p, 0, (size_t)(g->nz + 1) * sizeof(unsigned), stream));
+  mc_classify<<<nb, BLK, 0, stream>>>(sdf, d, (uint16_t*)m->info.p, (unsigned*)m->bsum.p, (unsigned*)m->layer.p);
+  mc_scan<<<1, 1024, 0, stream>>>((const unsigned*)m->bsum.p, nb, (unsigned*)m->boff.p, (unsigned long long*)m->totals.p,
+                                  (const unsigned*)m->layer.p, (unsigned*)m->layer_asc.p, g->nz);
+  DISN_HIP(ctx, hipGetLastError());
+  DISN_HIP(ctx, hipMemcpyAsync(m->tot, m->totals.p, sizeof(m->tot), hipMemcpyDeviceToHost, stream));
+  DISN_HIP(ctx, hipStreamSynchronize(stream));
+  m->sdf = sdf;
+  m->d = d;
+  m->nz_global = g->nz_global;
+  m->nb = nb;
+  m->counted = true;
+  counts[0] = m->tot[2];
+  counts[1] = m->tot[4];
+  counts[2] = m->tot[1];
+  return DISN_OK;
+}
+
+static int sort_tris(DisnCtx* ctx, McState* m, int* tris, uint64_t n, uint64_t max_index, hipStream_t stream) {
+  if (n < 2) return DISN_OK;
+  int bits = 1;
+  while (bits < 32 && (max_index >> bits)) ++bits;
+  const int passes = (bits + 7) / 8;
+  const unsigned nb = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+  DISN_TRY(disn_ensure(ctx, m->sort_tmp, n * 3 * sizeof(int)));
+  DISN_TRY(disn_ensure(ctx, m->sort_hist, (size_t)nb * 256 * sizeof(unsigned)));
+  int* a = tris;
+  int* b = (int*)m->sort_tmp.p;
+  unsigned* hist = (unsigned*)m->sort_hist.p;
+  for (int comp = 2; comp >= 0; --comp)
+    for (int ps = 0; ps < passes; ++ps) {
+      tri_sort_hist<<<nb, BLK, 0, stream>>>(a, n, comp, 8 * ps, hist, nb);
+      tri_sort_scan<<<1, 1024, 0, stream>>>(hist, nb * 256u);
+      tri_sort_scatter<<<nb, BLK, 0, stream>>>(a, b, n, comp, 8 * ps, hist, nb);
+      int* t = a; a = b; b = t;
+    }
+  if (a != tris) DISN_HIP(ctx, hipMemcpyAsync(tris, a, n * 3 * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  DISN_HIP(ctx, hipGetLastError());
+  return DISN_OK;
+}
+
+extern "C" int disn_mc_emit(DisnCtx* ctx, const double* bbox, uint64_t centre_base, uint64_t edge_base, double* verts,
+                            int64_t* keys, int32_t* tris, int sort, void* stream_) {
+  if (!ctx) return DISN_E_ARG;
+  McState* m = ctx->mc;
+  if (!m || !m->counted) return disn_fail(ctx, DISN_E_STATE, "disn_mc_emit: call disn_mc_count first");
+  if (!bbox) return disn_fail(ctx, DISN_E_ARG, "disn_mc_emit: null bbox");
+  const uint64_t nv = m->tot[2] + m->tot[4], nt = m->tot[1];
+  if ((nv && !verts) || (nt && !tris)) return disn_fail(ctx, DISN_E_ARG, "disn_mc_emit: null output buffer");
+  const uint64_t max_index = (centre_base + m->tot[2] > edge_base + m->tot[0] ? centre_base + m->tot[2] : edge_base + m->tot[0]);
+  if (max_index >= (1ull << 31)) return disn_fail(ctx, DISN_E_ARG, "disn_mc_emit: vertex indices exceed int32");
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  const Dims& d = m->d;
+  DISN_TRY(disn_ensure(ctx, m->vbase, (size_t)d.P * sizeof(unsigned)));
+  EmitArgs a;
+  const int ng[3] = {d.nx, d.ny, m->nz_global};
+  for (int q = 0; q < 3; ++q) {
+    a.lo[q] = bbox[q];
+    a.h[q] = (bbox[3 + q] - bbox[q]) / (double)(ng[q] - 1);
+  }
+  a.centre_base = centre_base;
+  a.edge_base = edge_base;
+  a.e_low = (unsigned)m->tot[3];
+  a.c_own = (unsigned)m->tot[2];
+  a.verts = verts;
+  a.keys = (long long*)keys;
+  a.tris = tris;
+  mc_vertices<<<m->nb, BLK, 0, stream>>>(m->sdf, d, (const uint16_t*)m->info.p, (const unsigned*)m->boff.p,
+                                         (unsigned*)m->vbase.p, a);
+  mc_triangles<<<m->nb, BLK, 0, stream>>>(m->sdf, d, (const uint16_t*)m->info.p, (const unsigned*)m->boff.p,
+                                          (const unsigned*)m->vbase.p, (const unsigned*)m->layer_asc.p, a);
+  DISN_HIP(ctx, hipGetLastError());
+  if (sort) DISN_TRY(sort_tris(ctx, m, tris, nt, max_index, stream));
+  return DISN_OK;
+}
+
+extern "C" int disn_mc_debug_info(DisnCtx* ctx, uint16_t* out, void* stream_) {
+  if (!ctx) return DISN_E_ARG;
+  McState* m = ctx->mc;
+  if (!m || !m->counted) return disn_fail(ctx, DISN_E_STATE, "disn_mc_debug_info: call disn_mc_count first");
+  if (!out) return disn_fail(ctx, DISN_E_ARG, "disn_mc_debug_info: null output");
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  DISN_HIP(ctx, hipMemcpyAsync(out, m->info.p, (size_t)m->d.P * sizeof(uint16_t), hipMemcpyDeviceToDevice,
+                               (hipStream_t)stream_));
+  return DISN_OK;
+}
+
+extern "C" int disn_sort_triangles(DisnCtx* ctx, int32_t* tris, uint64_t n, uint64_t max_index, void* stream_) {
+  if (!ctx) return DISN_E_ARG;
+  if (n && !tris) return disn_fail(ctx, DISN_E_ARG, "disn_sort_triangles: null buffer");
+  if (max_index >= (1ull << 31)) return disn_fail(ctx, DISN_E_ARG, "disn_sort_triangles: indices exceed int32");
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  return sort_tris(ctx, mc_state(ctx), tris, n, max_index, (hipStream_t)stream_);
+}

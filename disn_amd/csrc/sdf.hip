@@ -1,0 +1,652 @@
+// sdf.hip -- dense SDF evaluation for gfx950: camera projection, VGG feature
+// sampling and the two-stream point decoder of DISN, replacing the per-chunk
+// `sess.run(pred_sdf)` of the reference (demo/demo.py:312-326) and the graph it
+// executes (models/model_normalization.py:169-206,241-251;
+// models/sdfnet.py:69-92,171-190).
+//
+// Design:
+//  * Per image (disn_sdf_set_image): the five VGG maps are resized once to
+//    137x137 (TF1 legacy bilinear) into F137[18769][1472]; because
+//    fold2/conv1 of the local stream is linear before its ReLU, the image part
+//    of that layer is applied to the MAP instead of to every point:
+//    Pmap[18769][512] = F137 . W_l_f2c1[512:1984,:]  (fp32 MFMA GEMM).  Per
+//    point only a 4-corner bilinear blend of 512 pre-projected values remains.
+//    The global-feature part of the global stream's fold2/conv1 is a constant
+//    vector per image and is folded into that layer's bias.
+//  * Per point (sdf_decode): one wave owns 32 points and carries them through
+//    both streams with every activation in registers.  Products are
+//    W^T[32 features x 16 k] (A operand, streamed in fragment order) times
+//    activations[16 k x 32 points] (B operand) on v_mfma_f32_32x32x16_bf16;
+//    the 32x32 fp32 result has its point on the lane and its features in the
+//    16 registers, which is exactly the next layer's B operand (no LDS, no
+//    lane movement).  fp32 accuracy comes from a bf16 hi/lo split of both
+//    operands (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo, fp32 accumulate).
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float floatx16;
+typedef __attribute__((ext_vector_type(4))) float floatx4;
+
+constexpr int IMG = 137;                 // FLAGS.img_h/img_w (reference demo/demo.py:43-44)
+constexpr int NPIX = IMG * IMG;
+constexpr int FEAT_C = 1472;             // 64+128+256+512+512
+constexpr int LV_C[5] = {64, 128, 256, 512, 512};
+constexpr int LV_HW[5] = {224, 112, 56, 28, 14};
+constexpr int LV_OFF[5] = {0, 64, 192, 448, 960};
+
+// small per-stream parameter block (floats)
+constexpr int SP_W1 = 0;      // [64][4] = w[0][f], w[1][f], w[2][f], b[f]
+constexpr int SP_B2 = 256;    // [256]
+constexpr int SP_B3 = 512;    // [512]
+constexpr int SP_B4 = 1024;   // [512] (global stream: includes the hoisted global-feature term)
+constexpr int SP_B5 = 1536;   // [256]
+constexpr int SP_W6 = 1792;   // [256]
+constexpr int SP_B6 = 2048;   // [1]
+constexpr int SP_SIZE = 2052;
+
+// fragment pairs (hi 1 KiB + lo 1 KiB) per stream, in consumption order
+constexpr int PAIRS = 8 * 4 + 16 * (16 + 32) + 16 * 16;   // 1056 pairs = 2.06 MiB
+
+// ---- a1: projection (reference models/model_normalization.py:241-251) -----
+__device__ __forceinline__ void project(const float* T, float x, float y, float z, float& u, float& v) {
+  float a[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float s = __fadd_rn(__fmul_rn(x, T[c]), __fmul_rn(y, T[3 + c]));
+    s = __fadd_rn(s, __fmul_rn(z, T[6 + c]));
+    a[c] = __fadd_rn(s, T[9 + c]);
+  }
+  u = fminf(136.0f, fmaxf(0.0f, __fdiv_rn(a[0], a[2])));
+  v = fminf(136.0f, fmaxf(0.0f, __fdiv_rn(a[1], a[2])));
+}
+
+struct Corners {
+  int pix[4];    // pixel index (y*137+x), clamped
+  float w[4];    // resampler weights in the reference's summation order
+};
+
+// a3: tf.contrib.resampler corner weights (call sites reference
+// models/model_normalization.py:172-184); order: (fy,fx) (cy,cx) (cy,fx) (fy,cx)
+__device__ __forceinline__ Corners corners(float x, float y) {
+  Corners c;
+  float fx = floorf(x), fy = floorf(y);
+  float cx = fx + 1.0f, cy = fy + 1.0f;
+  float dx = __fsub_rn(cx, x), dy = __fsub_rn(cy, y);
+  int ifx = (int)fx, ify = (int)fy, icx = ifx + 1, icy = ify + 1;
+  bool in = x > -1.0f && y > -1.0f && x < (float)IMG && y < (float)IMG;
+  bool okfx = ifx >= 0 && ifx < IMG, okcx = icx >= 0 && icx < IMG;
+  bool okfy = ify >= 0 && ify < IMG, okcy = icy >= 0 && icy < IMG;
+  int xf = min(max(ifx, 0), IMG - 1), xc = min(max(icx, 0), IMG - 1);
+  int yf = min(max(ify, 0), IMG - 1), yc = min(max(icy, 0), IMG - 1);
+  float omdx = __fsub_rn(1.0f, dx), omdy = __fsub_rn(1.0f, dy);
+  c.pix[0] = yf * IMG + xf; c.w[0] = (in && okfy && okfx) ? __fmul_rn(dx, dy) : 0.0f;
+  c.pix[1] = yc * IMG + xc; c.w[1] = (in && okcy && okcx) ? __fmul_rn(omdx, omdy) : 0.0f;
+  c.pix[2] = yc * IMG + xf; c.w[2] = (in && okcy && okfx) ? __fmul_rn(dx, omdy) : 0.0f;
+  c.pix[3] = yf * IMG + xc; c.w[3] = (in && okfy && okcx) ? __fmul_rn(omdx, dy) : 0.0f;
+  return c;
+}
+
+__global__ void k_project(const float* __restrict__ pts, long long n, const float* __restrict__ Tg, float* __restrict__ xy) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float T[12];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) T[q] = Tg[q];
+  float u, v;
+  project(T, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], u, v);
+  xy[2 * i] = u;
+  xy[2 * i + 1] = v;
+}
+
+// ---- a2: TF1 legacy resize_bilinear, NHWC (call sites reference
+// models/model_normalization.py:72,171-183).  One thread per 4 channels.
+__global__ void k_resize(const float* __restrict__ in, int ih, int iw, int c, float* __restrict__ out, int oh, int ow,
+                         int out_stride, int out_off) {
+  const int c4 = c >> 2;
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)oh * ow * c4) return;
+  int ch = (int)(t % c4) * 4;
+  int ox = (int)((t / c4) % ow), oy = (int)(t / ((long long)c4 * ow));
+  const float sy = __fdiv_rn((float)ih, (float)oh), sx = __fdiv_rn((float)iw, (float)ow);
+  float fy = __fmul_rn((float)oy, sy), fx = __fmul_rn((float)ox, sx);
+  int ylo = (int)floorf(fy), xlo = (int)floorf(fx);
+  int yhi = min(ylo + 1, ih - 1), xhi = min(xlo + 1, iw - 1);
+  float ly = __fsub_rn(fy, (float)ylo), lx = __fsub_rn(fx, (float)xlo);
+  const floatx4 tl = *(const floatx4*)(in + ((size_t)ylo * iw + xlo) * c + ch);
+  const floatx4 tr = *(const floatx4*)(in + ((size_t)ylo * iw + xhi) * c + ch);
+  const floatx4 bl = *(const floatx4*)(in + ((size_t)yhi * iw + xlo) * c + ch);
+  const floatx4 br = *(const floatx4*)(in + ((size_t)yhi * iw + xhi) * c + ch);
+  floatx4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float top = __fadd_rn(tl[q], __fmul_rn(__fsub_rn(tr[q], tl[q]), lx));
+    float bot = __fadd_rn(bl[q], __fmul_rn(__fsub_rn(br[q], bl[q]), lx));
+    o[q] = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), ly));
+  }
+  *(floatx4*)(out + ((size_t)oy * ow + ox) * out_stride + out_off + ch) = o;
+}
+
+// ---- a3+a4: resampler + concat on the cached 137x137x1472 map ---------------
+__global__ void k_sample_features(const float* __restrict__ f137, const float* __restrict__ xy, long long n,
+                                  float* __restrict__ out) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * (FEAT_C / 4)) return;
+  long long p = t / (FEAT_C / 4);
+  int ch = (int)(t % (FEAT_C / 4)) * 4;
+  Corners c = corners(xy[2 * p], xy[2 * p + 1]);
+  floatx4 o = {0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    floatx4 v = *(const floatx4*)(f137 + (size_t)c.pix[q] * FEAT_C + ch);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(o[e], __fmul_rn(c.w[q], v[e]));
+  }
+  *(floatx4*)(out + (size_t)p * FEAT_C + ch) = o;
+}
+
+// ---- per-image GEMM: C[M][N] = A[M][K] . B[K][N], exact fp32 on
+// v_mfma_f32_32x32x2_f32.  128x128 tile per workgroup, 4 waves of 64x64.
+constexpr int GT = 128, GK = 16;
+__global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, const float* __restrict__ B,
+                                                   float* __restrict__ C, int M, int N, int K) {
+  __shared__ float As[GK][GT + 4];
+  __shared__ float Bs[GK][GT + 4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.0f;
+  for (int k0 = 0; k0 < K; k0 += GK) {
+    // A tile: 128 rows x 16 k; thread loads 2 float4 along k
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int idx = threadIdx.x + q * 256;       // 512 float4
+      int row = idx >> 2, kq = (idx & 3) * 4;
+      floatx4 v = {0, 0, 0, 0};
+      if (m0 + row < M) v = *(const floatx4*)(A + (size_t)(m0 + row) * K + k0 + kq);
+      As[kq + 0][row] = v[0]; As[kq + 1][row] = v[1]; As[kq + 2][row] = v[2]; As[kq + 3][row] = v[3];
+    }
+    // B tile: 16 k x 128 cols
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int idx = threadIdx.x + q * 256;
+      int kr = idx >> 5, cq = (idx & 31) * 4;
+      floatx4 v = *(const floatx4*)(B + (size_t)(k0 + kr) * N + n0 + cq);
+      *(floatx4*)&Bs[kr][cq] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 2) {
+      float a0 = As[kk + h][wm + r], a1 = As[kk + h][wm + 32 + r];
+      float b0 = Bs[kk + h][wn + r], b1 = Bs[kk + h][wn + 32 + r];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        int row = m0 + wm + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        int col = n0 + wn + b * 32 + r;
+        if (row < M) C[(size_t)row * N + col] = acc[a][b][g];
+      }
+}
+
+// hoisted global-feature term: b4g[n] = b[n] + sum_k global[k] * Wg[k][n] (k order, fp32)
+__global__ void k_global_bias(const float* __restrict__ gfeat, const float* __restrict__ Wg /*[1024][512]*/,
+                              const float* __restrict__ b, float* __restrict__ out) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= 512) return;
+  float s = 0.0f;
+  for (int k = 0; k < 1024; ++k) s = fmaf(gfeat[k], Wg[(size_t)k * 512 + n], s);
+  out[n] = s + b[n];
+}
+
+// ---- the decoder -----------------------------------------------------------
+struct DecodeArgs {
+  const uint4* ws[2];       // fragment streams: 0 global ("sdfprediction"), 1 local ("sdfprediction_imgfeat")
+  const float* sp[2];       // small parameter blocks
+  const float* pmap;        // [NPIX][512]
+  float T[12];
+  const float* pts;         // points mode: projection input [n][3]
+  const float* pts_rot;     // points mode: decoder input [n][3]
+  long long n;
+  int grid_mode, res, z0;   // grid mode: point p -> (i,j,k+z0) of a (res+1)^3 grid
+  double lo[3], hi[3], step[3];
+  int scale_out;            // 1: out = float(double(pred)/10)  (reference demo/demo.py:335,351)
+  float* out;
+};
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+__device__ __forceinline__ void load_pair(const uint4* __restrict__ ws, int idx, int lane, bf16x8& hi, bf16x8& lo) {
+  const uint4* p = ws + (size_t)idx * 128 + lane;
+  hi = as_bf16x8(p[0]);
+  lo = as_bf16x8(p[64]);
+}
+
+__device__ __forceinline__ floatx16 mma3(bf16x8 whi, bf16x8 wlo, bf16x8 xhi, bf16x8 xlo, floatx16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xhi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xlo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xhi, acc, 0, 0, 0);
+  return acc;
+}
+
+// ReLU + bf16 hi/lo split of accumulator registers 8s..8s+7 -> B fragment of k-step s
+__device__ __forceinline__ void relu_split(const floatx16& acc, int s, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = fmaxf(acc[8 * s + j], 0.0f);
+    __bf16 hb = (__bf16)v;
+    hi[j] = hb;
+    lo[j] = (__bf16)(v - (float)hb);
+  }
+}
+
+// accumulator initialised with a per-feature vector: reg g <-> feature base + (g&3) + 8(g>>2) + 4h
+__device__ __forceinline__ floatx16 bias_init(const float* __restrict__ b, int base, int h) {
+  floatx16 acc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    floatx4 v = *(const floatx4*)(b + base + 8 * q + 4 * h);
+    acc[4 * q + 0] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
+  }
+  return acc;
+}
+
+template <bool LOCAL>
+__device__ float stream_pass(const uint4* __restrict__ ws, const float* __restrict__ sp, const float* __restrict__ pmap,
+                             float px, float py, float pz, const Corners& cn, int lane) {
+  const int h = lane >> 5;
+  // fold1/conv1 (3 -> 64) on the VALU, written straight into B-fragment order
+  bf16x8 h1hi[4], h1lo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int f = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+      floatx4 w = *(const floatx4*)(sp + SP_W1 + 4 * f);
+      float v = fmaf(pz, w[2], fmaf(py, w[1], px * w[0])) + w[3];
+      v = fmaxf(v, 0.0f);
+      __bf16 hb = (__bf16)v;
+      h1hi[ks][j] = hb;
+      h1lo[ks][j] = (__bf16)(v - (float)hb);
+    }
+  }
+  // fold1/conv2 (64 -> 256): all of h2 stays resident as B fragments (16 k-steps)
+  int idx = 0;
+  bf16x8 h2hi[16], h2lo[16];
+#pragma unroll
+  for (int nb2 = 0; nb2 < 8; ++nb2) {
+    floatx16 acc2 = bias_init(sp + SP_B2, 32 * nb2, h);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 whi, wlo;
+      load_pair(ws, idx++, lane, whi, wlo);
+      acc2 = mma3(whi, wlo, h1hi[ks], h1lo[ks], acc2);
+    }
+    relu_split(acc2, 0, h2hi[2 * nb2], h2lo[2 * nb2]);
+    relu_split(acc2, 1, h2hi[2 * nb2 + 1], h2lo[2 * nb2 + 1]);
+  }
+  // fold1/conv3 (256 -> 512) chained into fold2/conv1 (point part, 512 -> 512):
+  // each finished 32-feature block of h3 is consumed at once as two k-steps of
+  // all sixteen fold2/conv1 accumulators, so h3 is never resident.
+  floatx16 acc4[16];
+#pragma unroll
+  for (int nb4 = 0; nb4 < 16; ++nb4) {
+    acc4[nb4] = bias_init(sp + SP_B4, 32 * nb4, h);
+    if (LOCAL) {
+      // image part of fold2/conv1: bilinear blend of the pre-projected map
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float* src = pmap + (size_t)cn.pix[c] * 512 + 32 * nb4 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          floatx4 v = *(const floatx4*)(src + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc4[nb4][4 * q + e] = fmaf(cn.w[c], v[e], acc4[nb4][4 * q + e]);
+        }
+      }
+    }
+  }
+#pragma unroll 1
+  for (int nb3 = 0; nb3 < 16; ++nb3) {
+    floatx16 acc3 = bias_init(sp + SP_B3, 32 * nb3, h);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      bf16x8 whi, wlo;
+      load_pair(ws, idx++, lane, whi, wlo);
+      acc3 = mma3(whi, wlo, h2hi[ks], h2lo[ks], acc3);
+    }
+    bf16x8 xhi[2], xlo[2];
+    relu_split(acc3, 0, xhi[0], xlo[0]);
+    relu_split(acc3, 1, xhi[1], xlo[1]);
+#pragma unroll
+    for (int nb4 = 0; nb4 < 16; ++nb4)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 whi, wlo;
+        load_pair(ws, idx++, lane, whi, wlo);
+        acc4[nb4] = mma3(whi, wlo, xhi[s], xlo[s], acc4[nb4]);
+      }
+  }
+  // fold2/conv2 (512 -> 256), consuming the fold2/conv1 accumulators block by block
+  floatx16 acc5[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) acc5[nb] = bias_init(sp + SP_B5, 32 * nb, h);
+#pragma unroll
+  for (int nb4 = 0; nb4 < 16; ++nb4) {
+    bf16x8 xhi[2], xlo[2];
+    relu_split(acc4[nb4], 0, xhi[0], xlo[0]);
+    relu_split(acc4[nb4], 1, xhi[1], xlo[1]);
+#pragma unroll
+    for (int nb5 = 0; nb5 < 8; ++nb5)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 whi, wlo;
+        load_pair(ws, idx++, lane, whi, wlo);
+        acc5[nb5] = mma3(whi, wlo, xhi[s], xlo[s], acc5[nb5]);
+      }
+  }
+  // fold2/conv5 (256 -> 1): this lane holds half of its point's features
+  float part = 0.0f;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      floatx4 w = *(const floatx4*)(sp + SP_W6 + 32 * nb + 8 * q + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part = fmaf(fmaxf(acc5[nb][4 * q + e], 0.0f), w[e], part);
+    }
+  part += __shfl_xor(part, 32, 64);
+  return part + sp[SP_B6];
+}
+
+__global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  long long p = tile * 32 + (lane & 31);
+  if (tile * 32 >= a.n) return;       // whole wave out of range (no workgroup barriers in this kernel)
+  const bool valid = p < a.n;
+  if (!valid) p = a.n - 1;
+  float x, y, z, xr, yr, zr;
+  if (a.grid_mode) {
+    // a0: np.linspace per axis in float64, cast to float32 (reference demo/demo.py:297-305)
+    const int n1 = a.res + 1;
+    int i = (int)(p % n1);
+    long long q = p / n1;
+    int j = (int)(q % n1);
+    int k = (int)(q / n1) + a.z0;
+    x = (float)(i == a.res ? a.hi[0] : __dadd_rn(__dmul_rn((double)i, a.step[0]), a.lo[0]));
+    y = (float)(j == a.res ? a.hi[1] : __dadd_rn(__dmul_rn((double)j, a.step[1]), a.lo[1]));
+    z = (float)(k == a.res ? a.hi[2] : __dadd_rn(__dmul_rn((double)k, a.step[2]), a.lo[2]));
+    xr = x; yr = y; zr = z;
+  } else {
+    x = a.pts[3 * p]; y = a.pts[3 * p + 1]; z = a.pts[3 * p + 2];
+    xr = a.pts_rot[3 * p]; yr = a.pts_rot[3 * p + 1]; zr = a.pts_rot[3 * p + 2];
+  }
+  float u, v;
+  project(a.T, x, y, z, u, v);
+  const Corners cn = corners(u, v);
+  float g = stream_pass<false>(a.ws[0], a.sp[0], a.pmap, xr, yr, zr, cn, lane);
+  float l = stream_pass<true>(a.ws[1], a.sp[1], a.pmap, xr, yr, zr, cn, lane);
+  float pred = __fadd_rn(g, l);   // reference models/model_normalization.py:204
+  if (valid && lane < 32) a.out[p] = a.scale_out ? (float)((double)pred / 10.0) : pred;
+}
+
+}  // namespace
+
+struct SdfState {
+  DevBuf ws[2], sp[2], f137, pmap, wimg, wglob, b4g, tmat;
+  bool have_weights = false, have_image = false;
+};
+
+void disn_sdf_state_free(DisnCtx* ctx) {
+  if (!ctx->sdf) return;
+  SdfState* s = ctx->sdf;
+  DevBuf* all[] = {&s->ws[0], &s->ws[1], &s->sp[0], &s->sp[1], &s->f137, &s->pmap, &s->wimg, &s->wglob, &s->b4g, &s->tmat};
+  for (DevBuf* b : all) disn_release(*b);
+  delete s;
+  ctx->sdf = nullptr;
+}
+
+static SdfState* sdf_state(DisnCtx* ctx) {
+  if (!ctx->sdf) ctx->sdf = new SdfState();
+  return ctx->sdf;
+}
+
+static inline uint16_t bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// one fragment pair of W[K][N] (row-major [Cin][Cout], rows krow0.. = this layer's
+// input features): n-block nb, k-step ks.  Lane (r,h) element j holds
+// W[32(ks>>1) + 16(ks&1) + 8(j>>2) + 4h + (j&3)][32nb + r]  (the accumulator-as-operand k order).
+static void pack_pair(std::vector<uint16_t>& out, const float* W, int N, int nb, int ks) {
+  size_t base = out.size();
+  out.resize(base + 1024);
+  for (int lane = 0; lane < 64; ++lane) {
+    int r = lane & 31, h = lane >> 5;
+    for (int j = 0; j < 8; ++j) {
+      int k = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+      float w = W[(size_t)k * N + 32 * nb + r];
+      uint16_t hi = bf16_rne(w);
+      uint16_t lo = bf16_rne(w - bf16_to_f32(hi));
+      out[base + lane * 8 + j] = hi;
+      out[base + 512 + lane * 8 + j] = lo;
+    }
+  }
+}
+
+static int upload(DisnCtx* ctx, DevBuf& b, const void* src, size_t bytes) {
+  DISN_TRY(disn_ensure(ctx, b, bytes));
+  DISN_HIP(ctx, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  return DISN_OK;
+}
+
+extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
+  if (!ctx) return DISN_E_ARG;
+  if (!w) return disn_fail(ctx, DISN_E_ARG, "disn_sdf_set_weights: null weights");
+  const float* const* ptrs = (const float* const*)w;
+  for (size_t i = 0; i < sizeof(DisnDecoderWeights) / sizeof(const float*); ++i)
+    if (!ptrs[i]) return disn_fail(ctx, DISN_E_ARG, "disn_sdf_set_weights: weight pointer %zu is null", i);
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  SdfState* s = sdf_state(ctx);
+  struct Stream { const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4, *w5, *b5, *w6, *b6; };
+  const Stream st[2] = {
+      {w->g_f1c1_w, w->g_f1c1_b, w->g_f1c2_w, w->g_f1c2_b, w->g_f1c3_w, w->g_f1c3_b, w->g_f2c1_w, w->g_f2c1_b,
+       w->g_f2c2_w, w->g_f2c2_b, w->g_f2c5_w, w->g_f2c5_b},
+      {w->l_f1c1_w, w->l_f1c1_b, w->l_f1c2_w, w->l_f1c2_b, w->l_f1c3_w, w->l_f1c3_b, w->l_f2c1_w, w->l_f2c1_b,
+       w->l_f2c2_w, w->l_f2c2_b, w->l_f2c5_w, w->l_f2c5_b}};
+  for (int t = 0; t < 2; ++t) {
+    const Stream& q = st[t];
+    std::vector<uint16_t> frag;
+    frag.reserve((size_t)PAIRS * 1024);
+    for (int nb2 = 0; nb2 < 8; ++nb2)
+      for (int ks = 0; ks < 4; ++ks) pack_pair(frag, q.w2, 256, nb2, ks);
+    for (int nb3 = 0; nb3 < 16; ++nb3) {
+      for (int ks = 0; ks < 16; ++ks) pack_pair(frag, q.w3, 512, nb3, ks);
+      for (int nb4 = 0; nb4 < 16; ++nb4)
+        for (int sft = 0; sft < 2; ++sft) pack_pair(frag, q.w4, 512, nb4, 2 * nb3 + sft);  // rows 0..511 = point features
+    }
+    for (int nb4 = 0; nb4 < 16; ++nb4)
+      for (int nb5 = 0; nb5 < 8; ++nb5)
+        for (int sft = 0; sft < 2; ++sft) pack_pair(frag, q.w5, 256, nb5, 2 * nb4 + sft);
+    if (frag.size() != (size_t)PAIRS * 1024) return disn_fail(ctx, DISN_E_STATE, "internal: fragment stream size");
+    DISN_TRY(upload(ctx, s->ws[t], frag.data(), frag.size() * sizeof(uint16_t)));
+    std::vector<float> sp(SP_SIZE, 0.0f);
+    for (int f = 0; f < 64; ++f) {
+      sp[SP_W1 + 4 * f + 0] = q.w1[0 * 64 + f];
+      sp[SP_W1 + 4 * f + 1] = q.w1[1 * 64 + f];
+      sp[SP_W1 + 4 * f + 2] = q.w1[2 * 64 + f];
+      sp[SP_W1 + 4 * f + 3] = q.b1[f];
+    }
+    memcpy(&sp[SP_B2], q.b2, 256 * sizeof(float));
+    memcpy(&sp[SP_B3], q.b3, 512 * sizeof(float));
+    memcpy(&sp[SP_B4], q.b4, 512 * sizeof(float));
+    memcpy(&sp[SP_B5], q.b5, 256 * sizeof(float));
+    memcpy(&sp[SP_W6], q.w6, 256 * sizeof(float));
+    sp[SP_B6] = q.b6[0];
+    DISN_TRY(upload(ctx, s->sp[t], sp.data(), sp.size() * sizeof(float)));
+  }
+  // per-image operands of the hoisted terms
+  DISN_TRY(upload(ctx, s->wglob, w->g_f2c1_w + (size_t)512 * 512, (size_t)1024 * 512 * sizeof(float)));
+  DISN_TRY(upload(ctx, s->wimg, w->l_f2c1_w + (size_t)512 * 512, (size_t)FEAT_C * 512 * sizeof(float)));
+  DISN_TRY(upload(ctx, s->b4g, w->g_f2c1_b, 512 * sizeof(float)));
+  s->have_weights = true;
+  s->have_image = false;
+  return DISN_OK;
+}
+
+extern "C" int disn_resize_bilinear(DisnCtx* ctx, const float* in, int ih, int iw, int c, float* out, int oh, int ow,
+                                    void* stream) {
+  if (!ctx) return DISN_E_ARG;
+  if (!in || !out || ih < 1 || iw < 1 || oh < 1 || ow < 1 || c < 4 || (c & 3))
+    return disn_fail(ctx, DISN_E_ARG, "disn_resize_bilinear: bad argument (channels must be a multiple of 4)");
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  long long n = (long long)oh * ow * (c / 4);
+  k_resize<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(in, ih, iw, c, out, oh, ow, c, 0);
+  DISN_HIP(ctx, hipGetLastError());
+  return DISN_OK;
+}
+
+extern "C" int disn_sdf_set_image(DisnCtx* ctx, const float* const feat_maps[5], const float* global_feat,
+                                  void* stream_) {
+  if (!ctx) return DISN_E_ARG;
+  SdfState* s = sdf_state(ctx);
+  if (!s->have_weights) return disn_fail(ctx, DISN_E_STATE, "disn_sdf_set_image: call disn_sdf_set_weights first");
+  if (!feat_maps || !global_feat) return disn_fail(ctx, DISN_E_ARG, "disn_sdf_set_image: null argument");
+  for (int l = 0; l < 5; ++l)
+    if (!feat_maps[l]) return disn_fail(ctx, DISN_E_ARG, "disn_sdf_set_image: feature map %d is null", l);
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  DISN_TRY(disn_ensure(ctx, s->f137, (size_t)NPIX * FEAT_C * sizeof(float)));
+  DISN_TRY(disn_ensure(ctx, s->pmap, (size_t)NPIX * 512 * sizeof(float)));
+  for (int l = 0; l < 5; ++l) {
+    long long n = (long long)NPIX * (LV_C[l] / 4);
+    k_resize<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(feat_maps[l], LV_HW[l], LV_HW[l], LV_C[l],
+                                                              (float*)s->f137.p, IMG, IMG, FEAT_C, LV_OFF[l]);
+  }
+  dim3 grid(512 / GT, (NPIX + GT - 1) / GT);
+  k_gemm_f32<<<grid, 256, 0, stream>>>((const float*)s->f137.p, (const float*)s->wimg.p, (float*)s->pmap.p, NPIX, 512,
+                                       FEAT_C);
+  k_global_bias<<<2, 256, 0, stream>>>(global_feat, (const float*)s->wglob.p, (const float*)s->b4g.p,
+                                       (float*)s->sp[0].p + SP_B4);
+  DISN_HIP(ctx, hipGetLastError());
+  s->have_image = true;
+  return DISN_OK;
+}
+
+static int launch_decode(DisnCtx* ctx, DecodeArgs& a, const float* trans_mat, hipStream_t stream) {
+  SdfState* s = ctx->sdf;
+  if (!s || !s->have_weights || !s->have_image)
+    return disn_fail(ctx, DISN_E_STATE, "SDF evaluation needs disn_sdf_set_weights and disn_sdf_set_image first");
+  if (!trans_mat) return disn_fail(ctx, DISN_E_ARG, "null trans_mat");
+  for (int q = 0; q < 12; ++q) a.T[q] = trans_mat[q];
+  a.ws[0] = (const uint4*)s->ws[0].p;
+  a.ws[1] = (const uint4*)s->ws[1].p;
+  a.sp[0] = (const float*)s->sp[0].p;
+  a.sp[1] = (const float*)s->sp[1].p;
+  a.pmap = (const float*)s->pmap.p;
+  if (a.n <= 0) return DISN_OK;
+  long long tiles = (a.n + 31) / 32;
+  long long blocks = (tiles + 3) / 4;
+  if (blocks > 0x7fffffffll) return disn_fail(ctx, DISN_E_ARG, "too many points for one launch");
+  sdf_decode<<<(unsigned)blocks, 256, 0, stream>>>(a);
+  DISN_HIP(ctx, hipGetLastError());
+  return DISN_OK;
+}
+
+extern "C" int disn_sdf_grid(DisnCtx* ctx, const float* trans_mat, const double* sdf_params, int res, int z0, int z1,
+                             float* sdf_out, void* stream) {
+  if (!ctx) return DISN_E_ARG;
+  if (!sdf_params || !sdf_out) return disn_fail(ctx, DISN_E_ARG, "disn_sdf_grid: null argument");
+  if (res < 1 || res > 2047 || z0 < 0 || z1 > res || z0 > z1)
+    return disn_fail(ctx, DISN_E_ARG, "disn_sdf_grid: bad res/z range (res=%d z0=%d z1=%d)", res, z0, z1);
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  DecodeArgs a{};
+  a.grid_mode = 1;
+  a.res = res;
+  a.z0 = z0;
+  for (int q = 0; q < 3; ++q) {
+    a.lo[q] = sdf_params[q];
+    a.hi[q] = sdf_params[3 + q];
+    a.step[q] = (sdf_params[3 + q] - sdf_params[q]) / (double)res;  // np.linspace: delta / div
+  }
+  a.n = (long long)(z1 - z0 + 1) * (res + 1) * (res + 1);
+  a.scale_out = 1;
+  a.out = sdf_out;
+  return launch_decode(ctx, a, trans_mat, (hipStream_t)stream);
+}
+
+extern "C" int disn_sdf_points(DisnCtx* ctx, const float* trans_mat, const float* pts, const float* pts_rot, int64_t n,
+                               float* out, void* stream) {
+  if (!ctx) return DISN_E_ARG;
+  if (n < 0 || (n && (!pts || !pts_rot || !out))) return disn_fail(ctx, DISN_E_ARG, "disn_sdf_points: bad argument");
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  DecodeArgs a{};
+  a.grid_mode = 0;
+  a.pts = pts;
+  a.pts_rot = pts_rot;
+  a.n = n;
+  a.scale_out = 0;
+  a.out = out;
+  return launch_decode(ctx, a, trans_mat, (hipStream_t)stream);
+}
+
+extern "C" int disn_project_points(DisnCtx* ctx, const float* trans_mat, const float* pts, int64_t n, float* xy_out,
+                                   void* stream_) {
+  if (!ctx) return DISN_E_ARG;
+  if (!trans_mat || n < 0 || (n && (!pts || !xy_out))) return disn_fail(ctx, DISN_E_ARG, "disn_project_points: bad argument");
+  if (n == 0) return DISN_OK;
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  SdfState* s = sdf_state(ctx);
+  DISN_TRY(disn_ensure(ctx, s->tmat, 12 * sizeof(float)));
+  DISN_HIP(ctx, hipMemcpyAsync(s->tmat.p, trans_mat, 12 * sizeof(float), hipMemcpyHostToDevice, stream));
+  k_project<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(pts, n, (const float*)s->tmat.p, xy_out);
+  DISN_HIP(ctx, hipGetLastError());
+  return DISN_OK;
+}
+
+extern "C" int disn_sample_features(DisnCtx* ctx, const float* xy, int64_t n, float* feat_out, void* stream) {
+  if (!ctx) return DISN_E_ARG;
+  SdfState* s = ctx->sdf;
+  if (!s || !s->have_image) return disn_fail(ctx, DISN_E_STATE, "disn_sample_features: call disn_sdf_set_image first");
+  if (n < 0 || (n && (!xy || !feat_out))) return disn_fail(ctx, DISN_E_ARG, "disn_sample_features: bad argument");
+  if (n == 0) return DISN_OK;
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  long long t = (long long)n * (FEAT_C / 4);
+  k_sample_features<<<(unsigned)((t + 255) / 256), 256, 0, (hipStream_t)stream>>>((const float*)s->f137.p, xy, n, feat_out);
+  DISN_HIP(ctx, hipGetLastError());
+  return DISN_OK;
+}

@@ -1,0 +1,174 @@
+/* disn.h -- C ABI of libdisn_hip.so: the MI355X (gfx950) replacement for the
+ * hot path of Xharlie/DISN's dense SDF-grid inference + isosurface extraction.
+ *
+ * The reference has no FFI for this path; it crosses two informal boundaries
+ *  which this header formalises:
+ *   1. `sess.run([pred_sdf, ...], feed_dict)` once per point chunk
+ *      (reference: demo/demo.py:312-326, test/create_sdf.py:224-289), and
+ *   2. `os.system("./isosurface/computeMarchingCubes in.dist out.obj -i iso")`
+ *      plus the .dist / OBJ file formats (reference: demo/demo.py:342-369).
+ * Every entry point names the reference lines it replaces.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative DISN_E_* code and records a message retrievable with
+ * disn_last_error(); no exceptions cross the boundary; no global state -- one
+ * DisnCtx per (thread, device).  Pointers marked DEVICE are hipMalloc'ed
+ * memory on the ctx's device and stay owned by the caller.  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  Calls are
+ * asynchronous on `stream` unless stated otherwise.
+ */
+#ifndef DISN_H
+#define DISN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DISN_OK 0
+#define DISN_E_ARG (-1)     /* bad argument (shape, null pointer, range) */
+#define DISN_E_HIP (-2)     /* a HIP runtime call failed */
+#define DISN_E_STATE (-3)   /* call order violated (e.g. emit before count) */
+#define DISN_E_IO (-4)      /* file could not be read / written / parsed */
+#define DISN_E_NOMEM (-5)
+
+typedef struct DisnCtx DisnCtx;
+
+/* ---- context ---------------------------------------------------------- */
+/* Replaces: tf.Session creation + CUDA_VISIBLE_DEVICES device choice
+ * (reference: demo/demo.py:86,142-151). */
+int disn_create(int device_id, DisnCtx** out);
+void disn_destroy(DisnCtx* ctx);
+const char* disn_last_error(const DisnCtx* ctx);
+const char* disn_version(void);
+
+/* ---- two-stream decoder weights --------------------------------------- */
+/* The 12 weight/bias pairs of the two decoders, fp32, each weight row-major
+ * [Cin][Cout] (= TF HWIO with H=W=1).  Names follow the reference variables:
+ *   g_* : scope "sdfprediction"          (reference: models/sdfnet.py:69-92)
+ *   l_* : scope "sdfprediction_imgfeat"  (reference: models/sdfnet.py:171-190)
+ *   f1c1/f1c2/f1c3 = fold1/conv{1,2,3}, f2c1/f2c2/f2c5 = fold2/conv{1,2,5}.
+ * Pointers may be HOST memory: disn_sdf_set_weights copies and re-packs them. */
+typedef struct DisnDecoderWeights {
+  const float *g_f1c1_w, *g_f1c1_b; /* [3][64],    [64]  */
+  const float *g_f1c2_w, *g_f1c2_b; /* [64][256],  [256] */
+  const float *g_f1c3_w, *g_f1c3_b; /* [256][512], [512] */
+  const float *g_f2c1_w, *g_f2c1_b; /* [1536][512] rows 0..511 point feat, 512..1535 global feat */
+  const float *g_f2c2_w, *g_f2c2_b; /* [512][256], [256] */
+  const float *g_f2c5_w, *g_f2c5_b; /* [256][1],   [1]   */
+  const float *l_f1c1_w, *l_f1c1_b;
+  const float *l_f1c2_w, *l_f1c2_b;
+  const float *l_f1c3_w, *l_f1c3_b;
+  const float *l_f2c1_w, *l_f2c1_b; /* [1984][512] rows 0..511 point feat, 512..1983 image feat */
+  const float *l_f2c2_w, *l_f2c2_b;
+  const float *l_f2c5_w, *l_f2c5_b;
+} DisnDecoderWeights;
+
+/* Replaces: tf.train.Saver.restore of the decoder variables
+ * (reference: demo/demo.py:153-165).  Host pointers; synchronous. */
+int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w);
+
+/* Per-image constants.  feat_maps = the five VGG end points conv1_2, conv2_2,
+ * conv3_3, conv4_3, conv5_3 as DEVICE fp32 NHWC at native resolution
+ * [224,224,64] [112,112,128] [56,56,256] [28,28,512] [14,14,512];
+ * global_feat = DEVICE fp32 [1024] (vgg fc8 embedding).
+ * Replaces the per-chunk re-evaluation of reference
+ * models/model_normalization.py:171-185 (five resize_bilinear to 137x137) and
+ * the tiled global feature of models/sdfnet.py:78-82: both are per-image
+ * constants and are computed once here. */
+int disn_sdf_set_image(DisnCtx* ctx, const float* const feat_maps[5], const float* global_feat,
+                       void* stream);
+
+/* Regular-grid SDF evaluation.  Replaces the chunk loop
+ * `for sp in range(SPLIT_SIZE): sess.run(...)` and the host-side
+ * `/ SDF_WEIGHT` (reference: demo/demo.py:292-335): grid points are generated
+ * on the device as np.linspace(lo,hi,res+1) per axis, x fastest
+ * (demo/demo.py:297-305), projected (models/model_normalization.py:241-251),
+ * sampled and decoded; the output is float32(float64(pred)/10).
+ *   trans_mat : HOST float[12], row-major 4x3 (demo/demo.py:272-276)
+ *   sdf_params: HOST double[6] = lo xyz, hi xyz (demo/demo.py:278)
+ *   res       : sdf_res (grid has res+1 points per axis)
+ *   z0,z1     : inclusive plane range to evaluate (z-slab); whole grid = 0,res
+ *   sdf_out   : DEVICE float[(z1-z0+1)*(res+1)^2], x fastest then y then z */
+int disn_sdf_grid(DisnCtx* ctx, const float* trans_mat, const double* sdf_params, int res,
+                  int z0, int z1, float* sdf_out, void* stream);
+
+/* Arbitrary query points (the literal sess.run signature, reference:
+ * demo/demo.py:317-325): sample_pc -> projection, sample_pc_rot -> decoder
+ * input.  pts / pts_rot: DEVICE float[n][3] (may alias); out: DEVICE float[n]
+ * = raw pred_sdf (NOT divided by 10, exactly what sess.run returns). */
+int disn_sdf_points(DisnCtx* ctx, const float* trans_mat, const float* pts, const float* pts_rot,
+                    int64_t n, float* out, void* stream);
+
+/* As-written building blocks, exported for row-by-row parity tests
+ * (SURVEY.md s8a rows a1-a4).  All DEVICE pointers. */
+/* a1: reference models/model_normalization.py:241-251. xy_out float[n][2]. */
+int disn_project_points(DisnCtx* ctx, const float* trans_mat, const float* pts, int64_t n,
+                        float* xy_out, void* stream);
+/* a2: tf.image.resize_bilinear(feat,(oh,ow)), align_corners=False, TF1 legacy
+ * (reference call sites models/model_normalization.py:72,171-183). NHWC. */
+int disn_resize_bilinear(DisnCtx* ctx, const float* in, int ih, int iw, int c, float* out, int oh,
+                         int ow, void* stream);
+/* a3+a4: tf.contrib.resampler.resampler on the five 137x137 maps + concat to
+ * 1472 channels (reference: models/model_normalization.py:172-190).  Uses the
+ * maps cached by disn_sdf_set_image.  feat_out float[n][1472]. */
+int disn_sample_features(DisnCtx* ctx, const float* xy, int64_t n, float* feat_out, void* stream);
+
+/* ---- marching cubes ---------------------------------------------------- */
+/* Slab description.  A whole grid is {nx,ny,nz, 0, nz, 0, nz}. */
+typedef struct DisnMcGrid {
+  int32_t nx, ny, nz;  /* points per axis PRESENT in the sdf buffer (x fastest) */
+  int32_t z_offset;    /* global plane index of local plane 0 */
+  int32_t nz_global;   /* planes of the whole grid (= sdf_res+1) */
+  int32_t own0, own1;  /* local planes [own0,own1) whose edge vertices and voxel
+                          layers this call owns; the rest is halo */
+} DisnMcGrid;
+
+/* Phase 1: classify + count.  Replaces MarchingCubes::compute's voxel pass of
+ * `computeMarchingCubes <dist> <obj> -i iso` (reference: demo/demo.py:365-369;
+ * spec SURVEY.md App. B.1-B.3).  SYNCHRONOUS (returns counts).
+ * counts[0]=centre vertices, [1]=edge vertices, [2]=triangles, owned only. */
+int disn_mc_count(DisnCtx* ctx, const float* sdf, const DisnMcGrid* grid, float iso,
+                  uint64_t counts[3], void* stream);
+
+/* Phase 2: emit.  Must follow disn_mc_count on the same ctx with the same sdf.
+ *   bbox        : HOST double[6] lo xyz, hi xyz of the WHOLE grid (.dist header)
+ *   centre_base : index given to this slab's first centre vertex
+ *   edge_base   : index given to this slab's first edge vertex
+ *                 (whole grid: centre_base=0, edge_base=counts[0])
+ *   verts       : DEVICE double[(counts[0]+counts[1])*3]; centre vertices
+ *                 first (descending k, then j, i), then edge vertices by key
+ *   keys        : DEVICE int64[counts[0]+counts[1]] signed vertex keys or NULL
+ *   tris        : DEVICE int32[counts[2]*3], indices already offset by the
+ *                 bases, smallest index first, sorted lexicographically when
+ *                 sort != 0. */
+int disn_mc_emit(DisnCtx* ctx, const double* bbox, uint64_t centre_base, uint64_t edge_base,
+                 double* verts, int64_t* keys, int32_t* tris, int sort, void* stream);
+
+/* Sub-table id per voxel (uint16, 0x3ff = no surface) + edge flags in bits
+ * 10..12, as left by the last disn_mc_count: DEVICE->DEVICE copy for
+ * case-index parity tests.  out: DEVICE uint16[nx*ny*nz]. */
+int disn_mc_debug_info(DisnCtx* ctx, uint16_t* out, void* stream);
+
+/* Lexicographic sort of n triangles (int32 x3) in place; used by the slab
+ * stitch to merge per-slab lists into the reference's global order
+ * (SURVEY.md App. B.6).  max_index bounds the values (limits radix passes). */
+int disn_sort_triangles(DisnCtx* ctx, int32_t* tris, uint64_t n, uint64_t max_index, void* stream);
+
+/* ---- file formats (host) ----------------------------------------------- */
+/* .dist writer/reader.  Replaces to_binary (reference: demo/demo.py:342-353;
+ * reader preprocessing/create_point_sdf_grid.py:29-51): int32 -res, res, res;
+ * 6 x float64 bbox; (res+1)^3 float32, x fastest. HOST pointers. */
+int disn_write_dist(const char* path, int res, const double* bbox, const float* values);
+int disn_read_dist_header(const char* path, int* res, double* bbox);
+int disn_read_dist(const char* path, float* values, size_t n_values);
+/* OBJ writer in the reference tool's text format:
+ * header comments, `v x y z` with 6 significant digits, `f a b c` 1-based. */
+int disn_write_obj(const char* path, const double* verts, uint64_t n_verts, const int32_t* tris,
+                   uint64_t n_tris);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISN_H */

@@ -1,0 +1,64 @@
+"""Pins the CPU marching-cubes oracle (oracle/mc_oracle.c) to the known answers
+the survey recorded from the reference tool, and checks mesh invariants."""
+import numpy as np
+import pytest
+
+import fields
+from oracle import mc
+
+
+def test_sphere_res8_known_answer():
+    # r=0.6 sphere, res 8 -> "#v 126 #t 248"
+    r = mc.marching_cubes(fields.sphere_field(8))
+    assert (len(r["verts"]), r["n_tri"]) == (126, 248)
+    assert len(r["verts"]) - 3 * r["n_tri"] // 2 + r["n_tri"] == 2   # Euler characteristic
+
+
+@pytest.mark.parametrize("res", [64, 128])
+def test_analytic_field_known_answer(res):
+    # SURVEY.md s6 / BASELINE.md: sizes printed by the reference tool
+    r = mc.marching_cubes(fields.analytic_field(res))
+    assert (len(r["verts"]), r["n_tri"]) == fields.KNOWN_ANALYTIC[res]
+    assert r["n_bad"] == 0
+    assert fields.mesh_is_closed_manifold(r["tris"])
+
+
+def test_ordering_rules():
+    # SURVEY.md App. B.6
+    r = mc.marching_cubes(fields.noise_field((10, 9, 11), seed=3))
+    assert r["n_centre"] > 0
+    k = r["keys"]
+    assert (np.diff(k) > 0).all()                      # ascending signed key, unique
+    assert (k[: r["n_centre"]] < 0).all() and (k[r["n_centre"]:] >= 0).all()
+    t = r["tris"]
+    assert (t[:, 0] < t[:, 1]).all() and (t[:, 0] < t[:, 2]).all()   # smallest index first
+    order = np.lexsort((t[:, 2], t[:, 1], t[:, 0]))
+    assert np.array_equal(order, np.arange(len(t)))
+    assert len(np.unique(t, axis=0)) == len(t)
+    assert fields.mesh_is_closed_manifold(t)
+
+
+def test_iso_nudge_and_bbox():
+    g = fields.sphere_field(8)
+    a = mc.marching_cubes(g, iso=0.05)
+    b = mc.marching_cubes(g - np.float32(0.05), iso=0.0)
+    assert np.array_equal(a["tris"], b["tris"])
+    # exact-iso samples count as outside (B.1): a plane through grid points
+    l = fields.lin(8)
+    z, y, x = np.meshgrid(l, l, l, indexing="ij")
+    p = mc.marching_cubes(x.astype(np.float32), iso=0.0)
+    assert p["n_tri"] > 0 and np.all(p["verts"][:, 0] <= 0.0)
+    # anisotropic bbox scales vertices linearly
+    s = mc.marching_cubes(g, bbox=(-2, -1, -3, 2, 1, 3))
+    u = mc.marching_cubes(g)
+    assert np.allclose(s["verts"], u["verts"] * np.array([2.0, 1.0, 3.0]), atol=1e-12)
+
+
+def test_golden_regression():
+    """tests/golden/mc_noise12.npz: oracle output frozen at the commit that
+    matched the reference's known answers (generator: tests/golden/make_golden.py)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mc_noise12.npz"))
+    r = mc.marching_cubes(z["grid"], iso=float(z["iso"]), bbox=tuple(z["bbox"]))
+    assert np.array_equal(r["tris"], z["tris"])
+    assert np.array_equal(r["verts"], z["verts"])
