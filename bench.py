@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- SDF query points/sec and ms per mesh (BASELINE.json metric).
+
+A step = one mesh: per-image precompute (137x137 resize + projected feature
+map), dense SDF evaluation of the (res+1)^3 grid, marching cubes with sorted
+output.  Inputs (VGG end points of a synthetic view, random-init decoder
+weights) are resident in HBM before the timed region; the VGG encoder itself
+is the once-per-image plumbing north_star excludes from the hot path.
+
+N=1: sdf_res=256 (BASELINE.json configs[1]).  N>1: ONE grid z-slab-sharded over
+the ranks with per-GPU points held at ~257^3 (res = round(256*N^(1/3)); N=8 is
+configs[2], sdf_res=512), RCCL broadcast of features + all-gather of counts,
+mesh assembled on rank 0 -> "weak" scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_FLOP_PER_POINT = 3671808        # SURVEY.md s8d (global term hoisted)
+MFMA_FLOP_PER_POINT = 3 * 2 * 2 * (64 * 256 + 256 * 512 + 512 * 512 + 512 * 256)   # executed bf16 MFMA flops (3-product split)
+PEAK_BF16_TFLOPS = 2500.0           # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(res, trans_mat, feats_np, gfeat_np, weights, iso, budget_s=12.0):
+    """The reference pipeline's stand-in on the host cores: oracle/net.py (torch-CPU fp32
+    restatement of the TF graph) on a bounded sample of the grid + oracle/mc_oracle.c on the
+    full grid.  kind="port": TensorFlow and the closed MC tool cannot run here."""
+    from oracle import mc, net
+    pts = net.grid_points(res)
+    P = len(pts)
+    n0 = 32768
+    t0 = time.time()
+    net.sdf_points(pts[:n0], pts[:n0], trans_mat, feats_np, gfeat_np, weights)
+    dt0 = time.time() - t0
+    n1 = int(min(P - n0, max(n0, (budget_s - dt0) / max(dt0, 1e-3) * n0)))
+    sel = np.linspace(0, P - 1, n1).astype(np.int64)
+    t0 = time.time()
+    net.sdf_points(pts[sel], pts[sel], trans_mat, feats_np, gfeat_np, weights)
+    dt1 = time.time() - t0
+    net_pps = n1 / dt1
+    return net_pps, n1, dt1, mc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--res", type=int, default=0, help="sdf_res (default 256 at N=1, round(256*N^(1/3)) otherwise)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from disn_amd import synth
+    from disn_amd.api import Context
+    from disn_amd.encoder import Vgg16Encoder
+    from disn_amd.pipeline import MeshPipeline, median_iso
+
+    res = args.res or (256 if world == 1 else int(round(256 * world ** (1.0 / 3.0))))
+    ctx = Context(local_rank)
+    weights = synth.decoder_weights(seed=0)
+    ctx.set_weights(weights)
+    enc = Vgg16Encoder(ctx, synth.vgg_weights(seed=0))
+    gfeat, feats = enc(synth.image(seed=0))          # once per image, outside the timed region
+    if world > 1 and rank != 0:                      # non-root ranks only hold receive buffers
+        feats = [torch.zeros_like(f) for f in feats]
+        gfeat = torch.zeros_like(gfeat)
+    pipe = MeshPipeline(ctx, rank, world, dist)
+    tm = synth.GT_TRANS_MAT
+
+    # iso: median of the predicted grid so that random-init weights give a surface
+    pipe.run(feats, gfeat, tm, res, want_mesh=False)
+    iso_t = torch.tensor([median_iso(pipe.last_sdf)], device=ctx.device)
+    if world > 1:
+        dist.broadcast(iso_t, src=0)
+    iso = float(iso_t.item())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        verts, tris = pipe.run(feats, gfeat, tm, res, iso)
+    pipe.time_decode = True
+    pipe.decode_events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        verts, tris = pipe.run(feats, gfeat, tm, res, iso)
+    barrier()
+    dt = time.perf_counter() - t0
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+    dt = float(dt_t.item())
+
+    points = (res + 1) ** 3
+    dec_ms = float(np.mean([a.elapsed_time(b) for a, b in pipe.decode_events]))
+    local_pts = pipe.last_sdf.numel()
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        alg_tflops = local_pts * ALG_FLOP_PER_POINT / (dec_ms * 1e-3) / 1e12
+        mfma_tflops = local_pts * MFMA_FLOP_PER_POINT / (dec_ms * 1e-3) / 1e12
+        out = {
+            "metric": "SDF query points/sec (node), ms per mesh incl. marching cubes",
+            "value": points / (dt / args.steps), "unit": "points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (bf16x3 split MFMA, f32 accumulate)", "data": "synthetic",
+            "config": {"workload": "sdf_res=%d two-stream, full sorted mesh output, %d z-slab(s)" % (res, world),
+                       "sdf_res": res, "points": points, "mesh_vertices": int(verts.shape[0]),
+                       "mesh_triangles": int(tris.shape[0]), "iso": iso,
+                       "per_gpu_points_incl_halo": local_pts},
+            "roofline": {"bound": "mfma", "kernel": "sdf_decode", "achieved": alg_tflops, "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": alg_tflops / PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel_ms": dec_ms, "alg_flop_per_point": ALG_FLOP_PER_POINT,
+                         "executed_mfma_tflops": mfma_tflops, "mfma_issue_frac": mfma_tflops / PEAK_BF16_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            torch.set_num_threads(min(16, os.cpu_count() or 1))
+            feats_np = [f.cpu().numpy() for f in feats]
+            net_pps, n1, dt1, mc = cpu_baseline(res, tm, feats_np, gfeat.cpu().numpy(), weights, iso)
+            sdf_np = pipe.last_sdf.cpu().numpy()
+            t1 = time.time()
+            ref = mc.marching_cubes(sdf_np, iso=iso)
+            mc_s = time.time() - t1
+            cpu_s = points / net_pps + mc_s
+            out["cpu_baseline"] = {
+                "value": points / cpu_s, "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "oracle/net.py on %d of %d grid points (%.1f s, scaled linearly) + oracle/mc_oracle.c on the "
+                          "full grid (%.2f s)" % (n1, points, dt1, mc_s),
+                "ms_per_mesh": cpu_s * 1e3,
+                "mesh_matches_gpu": bool(np.array_equal(ref["tris"], tris.cpu().numpy())),
+            }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("disn_amd: %s is missing -- the HIP extension is mandatory (no CPU fallback); "
                            "run `make -C disn_amd/csrc`" % LIB_PATH)
+    # torch bundles its own HIP runtime; it must be the one already loaded when
+    # libdisn_hip.so resolves libamdhip64 (two runtimes in one process do not share devices)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
