@@ -223,8 +223,8 @@ __global__ void k_global_bias(const float* __restrict__ gfeat, const float* __re
 
 // ---- the decoder -----------------------------------------------------------
 struct DecodeArgs {
-  const uint4* ws[2];       // fragment streams: 0 global ("sdfprediction"), 1 local ("sdfprediction_imgfeat")
-  const float* sp[2];       // small parameter blocks
+  const uint4* ws;          // fragment stream: [global stream 1056 pairs][local stream 1056 pairs], 2 KiB per pair
+  const float* sp;          // small parameter blocks [2][SP_SIZE]
   const float* pmap;        // [NPIX][512]
   float T[12];
   const float* pts;         // points mode: projection input [n][3]
@@ -236,19 +236,79 @@ struct DecodeArgs {
   float* out;
 };
 
+// ---- weight pipeline: global -> LDS ring by LDS-DMA, shared by the 4 waves ----
+constexpr int STAGE_PAIRS = 16;                          // fragment pairs per stage
+constexpr int STAGE_BYTES = STAGE_PAIRS * 2048;          // 32 KiB
+constexpr int NSLOT = 4;                                 // ring slots (3 stages in flight)
+constexpr int STAGES_PER_STREAM = PAIRS / STAGE_PAIRS;   // 66
+constexpr int STAGES_PER_TILE = 2 * STAGES_PER_STREAM;   // 132
+constexpr int SP_LDS_FLOATS = 2 * SP_SIZE;
+constexpr int LDS_BYTES = NSLOT * STAGE_BYTES + SP_LDS_FLOATS * 4;
+static_assert(PAIRS % STAGE_PAIRS == 0, "stream must be a whole number of stages");
+
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-__device__ __forceinline__ void load_pair(const uint4* __restrict__ ws, int idx, int lane, bf16x8& hi, bf16x8& lo) {
-  const uint4* p = ws + (size_t)idx * 128 + lane;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct Pipe {
+  const char* ws;      // global fragment stream (STAGES_PER_TILE stages, then it repeats)
+  char* ring;          // LDS ring base
+  int g;               // next stage to consume (counts across tiles)
+  int total;           // stages this workgroup will consume in all
+  int wave, lane;
+
+  // each wave copies a quarter of the stage: 8 x 1 KiB wave-instructions
+  __device__ __forceinline__ void issue(int stage) const {
+    const char* src = ws + (size_t)(stage % STAGES_PER_TILE) * STAGE_BYTES + wave * (STAGE_BYTES / 4) + lane * 16;
+    char* dst = ring + (stage % NSLOT) * STAGE_BYTES + wave * (STAGE_BYTES / 4);
+#pragma unroll
+    for (int i = 0; i < STAGE_BYTES / 4 / 1024; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                       (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+  }
+  // wait for stage g (own DMA), rendezvous, refill the slot everyone has just left
+  __device__ __forceinline__ const uint4* acquire() {
+    const int ahead = total - 1 - g;   // stages already issued beyond g: min(ahead, 2)
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (g + 3 < total) issue(g + 3);
+    const uint4* slot = (const uint4*)(ring + (g % NSLOT) * STAGE_BYTES);
+    ++g;
+    return slot;
+  }
+};
+
+// MFMA triples in VGPR-accumulator and AGPR-accumulator form.  Inline asm so the
+// accumulator file of each chain is ours to choose (the 512-wide fold2/conv1
+// block owns all 256 AGPRs, everything else accumulates in VGPRs).  Hazards the
+// compiler does not pad for an asm statement: a VALU-written operand needs two
+// wait states before the MFMA reads it (leading s_nop 1); the result needs the
+// drain below before any non-MFMA reader.
+__device__ __forceinline__ void mma3_v(floatx16& acc, bf16x8 whi, bf16x8 wlo, bf16x8 xhi, bf16x8 xlo) {
+  asm("s_nop 1\n\t"
+      "v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\t"
+      "v_mfma_f32_32x32x16_bf16 %0, %1, %4, %0\n\t"
+      "v_mfma_f32_32x32x16_bf16 %0, %1, %3, %0"
+      : "+v"(acc) : "v"(whi), "v"(wlo), "v"(xhi), "v"(xlo));
+}
+__device__ __forceinline__ void mma3_a(floatx16& acc, bf16x8 whi, bf16x8 wlo, bf16x8 xhi, bf16x8 xlo) {
+  asm("s_nop 1\n\t"
+      "v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\t"
+      "v_mfma_f32_32x32x16_bf16 %0, %1, %4, %0\n\t"
+      "v_mfma_f32_32x32x16_bf16 %0, %1, %3, %0"
+      : "+a"(acc) : "v"(whi), "v"(wlo), "v"(xhi), "v"(xlo));
+}
+// 8-pass MFMA result -> any other reader: 12+ wait states
+__device__ __forceinline__ void drain_v(floatx16& acc) { asm("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
+__device__ __forceinline__ void drain_a(floatx16& acc) { asm("s_nop 15\n\ts_nop 3" : "+a"(acc)); }
+
+__device__ __forceinline__ void frag_pair(const uint4* slot, int pair, int lane, bf16x8& hi, bf16x8& lo) {
+  const uint4* p = slot + pair * 128 + lane;
   hi = as_bf16x8(p[0]);
   lo = as_bf16x8(p[64]);
-}
-
-__device__ __forceinline__ floatx16 mma3(bf16x8 whi, bf16x8 wlo, bf16x8 xhi, bf16x8 xlo, floatx16 acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xhi, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xlo, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xhi, acc, 0, 0, 0);
-  return acc;
 }
 
 // ReLU + bf16 hi/lo split of accumulator registers 8s..8s+7 -> B fragment of k-step s
@@ -263,7 +323,7 @@ __device__ __forceinline__ void relu_split(const floatx16& acc, int s, bf16x8& h
 }
 
 // accumulator initialised with a per-feature vector: reg g <-> feature base + (g&3) + 8(g>>2) + 4h
-__device__ __forceinline__ floatx16 bias_init(const float* __restrict__ b, int base, int h) {
+__device__ __forceinline__ floatx16 bias_init(const float* b, int base, int h) {
   floatx16 acc;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -273,10 +333,11 @@ __device__ __forceinline__ floatx16 bias_init(const float* __restrict__ b, int b
   return acc;
 }
 
+// one decoder stream for the wave's 32 points; sp = this stream's parameters in LDS
 template <bool LOCAL>
-__device__ float stream_pass(const uint4* __restrict__ ws, const float* __restrict__ sp, const float* __restrict__ pmap,
-                             float px, float py, float pz, const Corners& cn, int lane) {
-  const int h = lane >> 5;
+__device__ float stream_pass(Pipe& pipe, const float* sp, const float* __restrict__ pmap, float px, float py, float pz,
+                             const Corners& cn) {
+  const int lane = pipe.lane, h = lane >> 5;
   // fold1/conv1 (3 -> 64) on the VALU, written straight into B-fragment order
   bf16x8 h1hi[4], h1lo[4];
 #pragma unroll
@@ -292,24 +353,27 @@ __device__ float stream_pass(const uint4* __restrict__ ws, const float* __restri
       h1lo[ks][j] = (__bf16)(v - (float)hb);
     }
   }
-  // fold1/conv2 (64 -> 256): all of h2 stays resident as B fragments (16 k-steps)
-  int idx = 0;
+  // fold1/conv2 (64 -> 256): 2 stages of 4 blocks; all of h2 stays resident as B fragments
   bf16x8 h2hi[16], h2lo[16];
 #pragma unroll
-  for (int nb2 = 0; nb2 < 8; ++nb2) {
-    floatx16 acc2 = bias_init(sp + SP_B2, 32 * nb2, h);
+  for (int st = 0; st < 2; ++st) {
+    const uint4* slot = pipe.acquire();
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 whi, wlo;
-      load_pair(ws, idx++, lane, whi, wlo);
-      acc2 = mma3(whi, wlo, h1hi[ks], h1lo[ks], acc2);
+    for (int b = 0; b < 4; ++b) {
+      const int nb2 = 4 * st + b;
+      floatx16 acc2 = bias_init(sp + SP_B2, 32 * nb2, h);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 whi, wlo;
+        frag_pair(slot, 4 * b + ks, lane, whi, wlo);
+        mma3_v(acc2, whi, wlo, h1hi[ks], h1lo[ks]);
+      }
+      drain_v(acc2);
+      relu_split(acc2, 0, h2hi[2 * nb2], h2lo[2 * nb2]);
+      relu_split(acc2, 1, h2hi[2 * nb2 + 1], h2lo[2 * nb2 + 1]);
     }
-    relu_split(acc2, 0, h2hi[2 * nb2], h2lo[2 * nb2]);
-    relu_split(acc2, 1, h2hi[2 * nb2 + 1], h2lo[2 * nb2 + 1]);
   }
-  // fold1/conv3 (256 -> 512) chained into fold2/conv1 (point part, 512 -> 512):
-  // each finished 32-feature block of h3 is consumed at once as two k-steps of
-  // all sixteen fold2/conv1 accumulators, so h3 is never resident.
+  // fold2/conv1 accumulators (point part, 512 wide): bias (+ image term) first
   floatx16 acc4[16];
 #pragma unroll
   for (int nb4 = 0; nb4 < 16; ++nb4) {
@@ -328,26 +392,34 @@ __device__ float stream_pass(const uint4* __restrict__ ws, const float* __restri
       }
     }
   }
+  // fold1/conv3 (256 -> 512) chained into fold2/conv1: each finished 32-feature
+  // block of h3 is consumed at once as two k-steps of all sixteen accumulators
 #pragma unroll 1
   for (int nb3 = 0; nb3 < 16; ++nb3) {
     floatx16 acc3 = bias_init(sp + SP_B3, 32 * nb3, h);
+    const uint4* slot = pipe.acquire();
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       bf16x8 whi, wlo;
-      load_pair(ws, idx++, lane, whi, wlo);
-      acc3 = mma3(whi, wlo, h2hi[ks], h2lo[ks], acc3);
+      frag_pair(slot, ks, lane, whi, wlo);
+      mma3_v(acc3, whi, wlo, h2hi[ks], h2lo[ks]);
     }
+    drain_v(acc3);
     bf16x8 xhi[2], xlo[2];
     relu_split(acc3, 0, xhi[0], xlo[0]);
     relu_split(acc3, 1, xhi[1], xlo[1]);
 #pragma unroll
-    for (int nb4 = 0; nb4 < 16; ++nb4)
+    for (int st = 0; st < 2; ++st) {
+      slot = pipe.acquire();
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 whi, wlo;
-        load_pair(ws, idx++, lane, whi, wlo);
-        acc4[nb4] = mma3(whi, wlo, xhi[s], xlo[s], acc4[nb4]);
-      }
+      for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 whi, wlo;
+          frag_pair(slot, 2 * b + s2, lane, whi, wlo);
+          mma3_a(acc4[8 * st + b], whi, wlo, xhi[s2], xlo[s2]);
+        }
+    }
   }
   // fold2/conv2 (512 -> 256), consuming the fold2/conv1 accumulators block by block
   floatx16 acc5[8];
@@ -355,82 +427,108 @@ __device__ float stream_pass(const uint4* __restrict__ ws, const float* __restri
   for (int nb = 0; nb < 8; ++nb) acc5[nb] = bias_init(sp + SP_B5, 32 * nb, h);
 #pragma unroll
   for (int nb4 = 0; nb4 < 16; ++nb4) {
+    drain_a(acc4[nb4]);
     bf16x8 xhi[2], xlo[2];
     relu_split(acc4[nb4], 0, xhi[0], xlo[0]);
     relu_split(acc4[nb4], 1, xhi[1], xlo[1]);
+    const uint4* slot = pipe.acquire();
 #pragma unroll
     for (int nb5 = 0; nb5 < 8; ++nb5)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 whi, wlo;
-        load_pair(ws, idx++, lane, whi, wlo);
-        acc5[nb5] = mma3(whi, wlo, xhi[s], xlo[s], acc5[nb5]);
+        frag_pair(slot, 2 * nb5 + s2, lane, whi, wlo);
+        mma3_v(acc5[nb5], whi, wlo, xhi[s2], xlo[s2]);
       }
   }
   // fold2/conv5 (256 -> 1): this lane holds half of its point's features
   float part = 0.0f;
 #pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
+  for (int nb = 0; nb < 8; ++nb) {
+    drain_v(acc5[nb]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       floatx4 w = *(const floatx4*)(sp + SP_W6 + 32 * nb + 8 * q + 4 * h);
 #pragma unroll
       for (int e = 0; e < 4; ++e) part = fmaf(fmaxf(acc5[nb][4 * q + e], 0.0f), w[e], part);
     }
+  }
   part += __shfl_xor(part, 32, 64);
   return part + sp[SP_B6];
 }
 
+// persistent: one workgroup (4 waves x 32 points) per CU, tiles dealt round-robin
 __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
-  const int lane = threadIdx.x & 63;
-  const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  long long p = tile * 32 + (lane & 31);
-  if (tile * 32 >= a.n) return;       // whole wave out of range (no workgroup barriers in this kernel)
-  const bool valid = p < a.n;
-  if (!valid) p = a.n - 1;
-  float x, y, z, xr, yr, zr;
-  if (a.grid_mode) {
-    // a0: np.linspace per axis in float64, cast to float32 (reference demo/demo.py:297-305)
-    const int n1 = a.res + 1;
-    int i = (int)(p % n1);
-    long long q = p / n1;
-    int j = (int)(q % n1);
-    int k = (int)(q / n1) + a.z0;
-    x = (float)(i == a.res ? a.hi[0] : __dadd_rn(__dmul_rn((double)i, a.step[0]), a.lo[0]));
-    y = (float)(j == a.res ? a.hi[1] : __dadd_rn(__dmul_rn((double)j, a.step[1]), a.lo[1]));
-    z = (float)(k == a.res ? a.hi[2] : __dadd_rn(__dmul_rn((double)k, a.step[2]), a.lo[2]));
-    xr = x; yr = y; zr = z;
-  } else {
-    x = a.pts[3 * p]; y = a.pts[3 * p + 1]; z = a.pts[3 * p + 2];
-    xr = a.pts_rot[3 * p]; yr = a.pts_rot[3 * p + 1]; zr = a.pts_rot[3 * p + 2];
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* sp_lds = (float*)(lds + NSLOT * STAGE_BYTES);
+  for (int i = threadIdx.x; i < SP_LDS_FLOATS; i += 256) sp_lds[i] = a.sp[i];
+  const long long ntiles = (a.n + 127) / 128;
+  const long long mine = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;   // >= 1: grid <= ntiles
+  Pipe pipe;
+  pipe.ws = (const char*)a.ws;
+  pipe.ring = lds;
+  pipe.g = 0;
+  pipe.total = (int)(mine * STAGES_PER_TILE);
+  pipe.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  pipe.lane = threadIdx.x & 63;
+  pipe.issue(0);
+  pipe.issue(1);
+  pipe.issue(2);
+  __syncthreads();   // sp_lds visible (plain barrier: drains the three stages once, harmless)
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    long long p = tile * 128 + pipe.wave * 32 + (pipe.lane & 31);
+    const bool valid = p < a.n;
+    if (!valid) p = a.n - 1;
+    float x, y, z, xr, yr, zr;
+    if (a.grid_mode) {
+      // a0: np.linspace per axis in float64, cast to float32 (reference demo/demo.py:297-305)
+      const int n1 = a.res + 1;
+      int i = (int)(p % n1);
+      long long q = p / n1;
+      int j = (int)(q % n1);
+      int k = (int)(q / n1) + a.z0;
+      x = (float)(i == a.res ? a.hi[0] : __dadd_rn(__dmul_rn((double)i, a.step[0]), a.lo[0]));
+      y = (float)(j == a.res ? a.hi[1] : __dadd_rn(__dmul_rn((double)j, a.step[1]), a.lo[1]));
+      z = (float)(k == a.res ? a.hi[2] : __dadd_rn(__dmul_rn((double)k, a.step[2]), a.lo[2]));
+      xr = x; yr = y; zr = z;
+    } else {
+      x = a.pts[3 * p]; y = a.pts[3 * p + 1]; z = a.pts[3 * p + 2];
+      xr = a.pts_rot[3 * p]; yr = a.pts_rot[3 * p + 1]; zr = a.pts_rot[3 * p + 2];
+    }
+    float u, v;
+    project(a.T, x, y, z, u, v);
+    const Corners cn = corners(u, v);
+    float g = stream_pass<false>(pipe, sp_lds, a.pmap, xr, yr, zr, cn);
+    float l = stream_pass<true>(pipe, sp_lds + SP_SIZE, a.pmap, xr, yr, zr, cn);
+    float pred = __fadd_rn(g, l);   // reference models/model_normalization.py:204
+    if (valid && pipe.lane < 32) a.out[p] = a.scale_out ? (float)((double)pred / 10.0) : pred;
   }
-  float u, v;
-  project(a.T, x, y, z, u, v);
-  const Corners cn = corners(u, v);
-  float g = stream_pass<false>(a.ws[0], a.sp[0], a.pmap, xr, yr, zr, cn, lane);
-  float l = stream_pass<true>(a.ws[1], a.sp[1], a.pmap, xr, yr, zr, cn, lane);
-  float pred = __fadd_rn(g, l);   // reference models/model_normalization.py:204
-  if (valid && lane < 32) a.out[p] = a.scale_out ? (float)((double)pred / 10.0) : pred;
 }
 
 }  // namespace
 
 struct SdfState {
-  DevBuf ws[2], sp[2], f137, pmap, wimg, wglob, b4g, tmat;
+  DevBuf ws, sp, f137, pmap, wimg, wglob, b4g, tmat;
+  int num_cu = 256;
   bool have_weights = false, have_image = false;
 };
 
 void disn_sdf_state_free(DisnCtx* ctx) {
   if (!ctx->sdf) return;
   SdfState* s = ctx->sdf;
-  DevBuf* all[] = {&s->ws[0], &s->ws[1], &s->sp[0], &s->sp[1], &s->f137, &s->pmap, &s->wimg, &s->wglob, &s->b4g, &s->tmat};
+  DevBuf* all[] = {&s->ws, &s->sp, &s->f137, &s->pmap, &s->wimg, &s->wglob, &s->b4g, &s->tmat};
   for (DevBuf* b : all) disn_release(*b);
   delete s;
   ctx->sdf = nullptr;
 }
 
 static SdfState* sdf_state(DisnCtx* ctx) {
-  if (!ctx->sdf) ctx->sdf = new SdfState();
+  if (!ctx->sdf) {
+    ctx->sdf = new SdfState();
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cu > 0)
+      ctx->sdf->num_cu = cu;
+  }
   return ctx->sdf;
 }
 
@@ -502,7 +600,9 @@ extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
       for (int nb5 = 0; nb5 < 8; ++nb5)
         for (int sft = 0; sft < 2; ++sft) pack_pair(frag, q.w5, 256, nb5, 2 * nb4 + sft);
     if (frag.size() != (size_t)PAIRS * 1024) return disn_fail(ctx, DISN_E_STATE, "internal: fragment stream size");
-    DISN_TRY(upload(ctx, s->ws[t], frag.data(), frag.size() * sizeof(uint16_t)));
+    DISN_TRY(disn_ensure(ctx, s->ws, (size_t)2 * PAIRS * 2048));
+    DISN_HIP(ctx, hipMemcpy((char*)s->ws.p + (size_t)t * PAIRS * 2048, frag.data(), frag.size() * sizeof(uint16_t),
+                            hipMemcpyHostToDevice));
     std::vector<float> sp(SP_SIZE, 0.0f);
     for (int f = 0; f < 64; ++f) {
       sp[SP_W1 + 4 * f + 0] = q.w1[0 * 64 + f];
@@ -516,7 +616,9 @@ extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
     memcpy(&sp[SP_B5], q.b5, 256 * sizeof(float));
     memcpy(&sp[SP_W6], q.w6, 256 * sizeof(float));
     sp[SP_B6] = q.b6[0];
-    DISN_TRY(upload(ctx, s->sp[t], sp.data(), sp.size() * sizeof(float)));
+    DISN_TRY(disn_ensure(ctx, s->sp, (size_t)2 * SP_SIZE * sizeof(float)));
+    DISN_HIP(ctx, hipMemcpy((float*)s->sp.p + (size_t)t * SP_SIZE, sp.data(), sp.size() * sizeof(float),
+                            hipMemcpyHostToDevice));
   }
   // per-image operands of the hoisted terms
   DISN_TRY(upload(ctx, s->wglob, w->g_f2c1_w + (size_t)512 * 512, (size_t)1024 * 512 * sizeof(float)));
@@ -560,7 +662,7 @@ extern "C" int disn_sdf_set_image(DisnCtx* ctx, const float* const feat_maps[5],
   k_gemm_f32<<<grid, 256, 0, stream>>>((const float*)s->f137.p, (const float*)s->wimg.p, (float*)s->pmap.p, NPIX, 512,
                                        FEAT_C);
   k_global_bias<<<2, 256, 0, stream>>>(global_feat, (const float*)s->wglob.p, (const float*)s->b4g.p,
-                                       (float*)s->sp[0].p + SP_B4);
+                                       (float*)s->sp.p + SP_B4);
   DISN_HIP(ctx, hipGetLastError());
   s->have_image = true;
   return DISN_OK;
@@ -572,16 +674,15 @@ static int launch_decode(DisnCtx* ctx, DecodeArgs& a, const float* trans_mat, hi
     return disn_fail(ctx, DISN_E_STATE, "SDF evaluation needs disn_sdf_set_weights and disn_sdf_set_image first");
   if (!trans_mat) return disn_fail(ctx, DISN_E_ARG, "null trans_mat");
   for (int q = 0; q < 12; ++q) a.T[q] = trans_mat[q];
-  a.ws[0] = (const uint4*)s->ws[0].p;
-  a.ws[1] = (const uint4*)s->ws[1].p;
-  a.sp[0] = (const float*)s->sp[0].p;
-  a.sp[1] = (const float*)s->sp[1].p;
+  a.ws = (const uint4*)s->ws.p;
+  a.sp = (const float*)s->sp.p;
   a.pmap = (const float*)s->pmap.p;
   if (a.n <= 0) return DISN_OK;
-  long long tiles = (a.n + 31) / 32;
-  long long blocks = (tiles + 3) / 4;
-  if (blocks > 0x7fffffffll) return disn_fail(ctx, DISN_E_ARG, "too many points for one launch");
-  sdf_decode<<<(unsigned)blocks, 256, 0, stream>>>(a);
+  const long long tiles = (a.n + 127) / 128;
+  if (tiles * STAGES_PER_TILE > 0x7fffffffll) return disn_fail(ctx, DISN_E_ARG, "too many points for one launch");
+  const unsigned blocks = (unsigned)(tiles < s->num_cu ? tiles : s->num_cu);
+  DISN_HIP(ctx, hipFuncSetAttribute((const void*)sdf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  sdf_decode<<<blocks, 256, LDS_BYTES, stream>>>(a);
   DISN_HIP(ctx, hipGetLastError());
   return DISN_OK;
 }
