@@ -240,6 +240,7 @@ struct DecodeArgs {
 constexpr int STAGE_PAIRS = 16;                          // fragment pairs per stage
 constexpr int STAGE_BYTES = STAGE_PAIRS * 2048;          // 32 KiB
 constexpr int NSLOT = 4;                                 // ring slots (3 stages in flight)
+constexpr int PF = 2;                                    // fragment pairs read ahead of the MFMA triple that uses them
 constexpr int STAGES_PER_STREAM = PAIRS / STAGE_PAIRS;   // 66
 constexpr int STAGES_PER_TILE = 2 * STAGES_PER_STREAM;   // 132
 constexpr int SP_LDS_FLOATS = 2 * SP_SIZE;
@@ -261,10 +262,15 @@ struct Pipe {
   __device__ __forceinline__ void issue(int stage) const {
     const char* src = ws + (size_t)(stage % STAGES_PER_TILE) * STAGE_BYTES + wave * (STAGE_BYTES / 4) + lane * 16;
     char* dst = ring + (stage % NSLOT) * STAGE_BYTES + wave * (STAGE_BYTES / 4);
+    const unsigned dst32 = (unsigned)(size_t)(lds_ptr_t)dst;   // wave-uniform LDS byte address
 #pragma unroll
-    for (int i = 0; i < STAGE_BYTES / 4 / 1024; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
-                                       (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+    for (int i = 0; i < STAGE_BYTES / 4 / 1024; ++i) {
+      // LDS-DMA in asm so that hipcc does not count it: its own bookkeeping would drain
+      // vmcnt(0) before every ds_read.  M0 (LDS base) is set and restored in the same statement.
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src + i * 1024), "s"(dst32 + i * 1024) : "memory");
+    }
   }
   // wait for stage g (own DMA), rendezvous, refill the slot everyone has just left
   __device__ __forceinline__ const uint4* acquire() {
@@ -362,12 +368,11 @@ __device__ float stream_pass(Pipe& pipe, const float* sp, const float* __restric
     for (int b = 0; b < 4; ++b) {
       const int nb2 = 4 * st + b;
       floatx16 acc2 = bias_init(sp + SP_B2, 32 * nb2, h);
+      bf16x8 whi[4], wlo[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 whi, wlo;
-        frag_pair(slot, 4 * b + ks, lane, whi, wlo);
-        mma3_v(acc2, whi, wlo, h1hi[ks], h1lo[ks]);
-      }
+      for (int ks = 0; ks < 4; ++ks) frag_pair(slot, 4 * b + ks, lane, whi[ks], wlo[ks]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) mma3_v(acc2, whi[ks], wlo[ks], h1hi[ks], h1lo[ks]);
       drain_v(acc2);
       relu_split(acc2, 0, h2hi[2 * nb2], h2lo[2 * nb2]);
       relu_split(acc2, 1, h2hi[2 * nb2 + 1], h2lo[2 * nb2 + 1]);
@@ -398,11 +403,15 @@ __device__ float stream_pass(Pipe& pipe, const float* sp, const float* __restric
   for (int nb3 = 0; nb3 < 16; ++nb3) {
     floatx16 acc3 = bias_init(sp + SP_B3, 32 * nb3, h);
     const uint4* slot = pipe.acquire();
+    {
+      bf16x8 whi[PF + 1], wlo[PF + 1];
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      bf16x8 whi, wlo;
-      frag_pair(slot, ks, lane, whi, wlo);
-      mma3_v(acc3, whi, wlo, h2hi[ks], h2lo[ks]);
+      for (int ks = 0; ks < PF; ++ks) frag_pair(slot, ks, lane, whi[ks], wlo[ks]);
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks + PF < 16) frag_pair(slot, ks + PF, lane, whi[(ks + PF) % (PF + 1)], wlo[(ks + PF) % (PF + 1)]);
+        mma3_v(acc3, whi[ks % (PF + 1)], wlo[ks % (PF + 1)], h2hi[ks], h2lo[ks]);
+      }
     }
     drain_v(acc3);
     bf16x8 xhi[2], xlo[2];
@@ -411,14 +420,14 @@ __device__ float stream_pass(Pipe& pipe, const float* sp, const float* __restric
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       slot = pipe.acquire();
+      bf16x8 whi[PF + 1], wlo[PF + 1];
 #pragma unroll
-      for (int b = 0; b < 8; ++b)
+      for (int t = 0; t < PF; ++t) frag_pair(slot, t, lane, whi[t], wlo[t]);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          bf16x8 whi, wlo;
-          frag_pair(slot, 2 * b + s2, lane, whi, wlo);
-          mma3_a(acc4[8 * st + b], whi, wlo, xhi[s2], xlo[s2]);
-        }
+      for (int t = 0; t < 16; ++t) {
+        if (t + PF < 16) frag_pair(slot, t + PF, lane, whi[(t + PF) % (PF + 1)], wlo[(t + PF) % (PF + 1)]);
+        mma3_a(acc4[8 * st + (t >> 1)], whi[t % (PF + 1)], wlo[t % (PF + 1)], xhi[t & 1], xlo[t & 1]);
+      }
     }
   }
   // fold2/conv2 (512 -> 256), consuming the fold2/conv1 accumulators block by block
@@ -432,14 +441,14 @@ __device__ float stream_pass(Pipe& pipe, const float* sp, const float* __restric
     relu_split(acc4[nb4], 0, xhi[0], xlo[0]);
     relu_split(acc4[nb4], 1, xhi[1], xlo[1]);
     const uint4* slot = pipe.acquire();
+    bf16x8 whi[PF + 1], wlo[PF + 1];
 #pragma unroll
-    for (int nb5 = 0; nb5 < 8; ++nb5)
+    for (int t = 0; t < PF; ++t) frag_pair(slot, t, lane, whi[t], wlo[t]);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 whi, wlo;
-        frag_pair(slot, 2 * nb5 + s2, lane, whi, wlo);
-        mma3_v(acc5[nb5], whi, wlo, xhi[s2], xlo[s2]);
-      }
+    for (int t = 0; t < 16; ++t) {
+      if (t + PF < 16) frag_pair(slot, t + PF, lane, whi[(t + PF) % (PF + 1)], wlo[(t + PF) % (PF + 1)]);
+      mma3_v(acc5[t >> 1], whi[t % (PF + 1)], wlo[t % (PF + 1)], xhi[t & 1], xlo[t & 1]);
+    }
   }
   // fold2/conv5 (256 -> 1): this lane holds half of its point's features
   float part = 0.0f;
