@@ -1,0 +1,111 @@
+"""`demo.py` surface of the reference (reference: demo/demo.py:26-65,123-193,261-369)
+on the HIP path:  python -m disn_amd.demo --sdf_res 256 --img_feat_twostream
+
+Kept flags: --sdf_res --img_feat_twostream --cam_est --log_dir --cam_log_dir --iso
+--img_h --img_w --gpu (+ --image, --out, --ngpu is `torchrun --nproc-per-node`).
+Without a checkpoint reader the decoder / encoder run
+on seeded random-init weights and the tool says so; iso then defaults to the
+grid median so that a surface exists.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+
+def read_image(path):
+    """(137,137,3) float32 in [0,1], BGR channel order like cv2.imread (reference demo/demo.py:263-264)."""
+    from PIL import Image
+    img = np.asarray(Image.open(path))
+    if img.ndim == 2:
+        img = np.stack([img] * 3, -1)
+    img = img[:, :, :3][:, :, ::-1]          # RGB(A) -> BGR
+    if img.shape[:2] != (137, 137):
+        raise SystemExit("demo: image must be 137x137 (got %s)" % (img.shape[:2],))
+    return np.ascontiguousarray(img).astype(np.uint8).astype(np.float32) / np.float32(255.0)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--gpu", type=str, default="0")
+    ap.add_argument("--sdf_res", type=int, default=64)
+    ap.add_argument("--img_feat_twostream", action="store_true")
+    ap.add_argument("--cam_est", action="store_true")
+    ap.add_argument("--log_dir", default="checkpoint/SDF_DISN")
+    ap.add_argument("--cam_log_dir", default="cam_est/checkpoint/cam_DISN")
+    ap.add_argument("--iso", type=float, default=None)
+    ap.add_argument("--img_h", type=int, default=137)
+    ap.add_argument("--img_w", type=int, default=137)
+    ap.add_argument("--image", default=None, help="137x137 PNG (default: seeded synthetic view)")
+    ap.add_argument("--out", default="demo/result.obj")
+    ap.add_argument("--seed", type=int, default=0)
+    FLAGS = ap.parse_args(argv)
+    if not FLAGS.img_feat_twostream:
+        raise SystemExit("demo: only the two-stream decoder (--img_feat_twostream) is built (SURVEY.md s2 row 3)")
+    if (FLAGS.img_h, FLAGS.img_w) != (137, 137):
+        raise SystemExit("demo: the feature pyramid is sampled at 137x137 (reference default)")
+
+    from . import api, synth
+    from .encoder import Vgg16Encoder
+    from .pipeline import MeshPipeline, median_iso
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dev = int(os.environ.get("LOCAL_RANK", FLAGS.gpu.split(",")[0]))
+    dist = None
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    log = (lambda *a: print(*a, flush=True)) if rank == 0 else (lambda *a: None)
+
+    ctx = api.Context(dev)
+    ckpt = os.path.join(FLAGS.log_dir, "checkpoint")
+    if os.path.exists(ckpt):
+        raise SystemExit("demo: TF checkpoint reading is the next scope row (SURVEY.md s8f1); remove --log_dir "
+                         "to run on random-init weights")
+    log("demo: no checkpoint at %s -> seeded random-init decoder/encoder weights (seed %d)" % (FLAGS.log_dir, FLAGS.seed))
+    ctx.set_weights(synth.decoder_weights(FLAGS.seed))
+    enc = Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed))
+    img = read_image(FLAGS.image) if FLAGS.image else synth.image(FLAGS.seed)
+    if FLAGS.cam_est:
+        raise SystemExit("demo: the camera estimator forward is the next scope row (SURVEY.md s8f2); "
+                         "run without --cam_est to use the demo's ground-truth camera")
+    log("here we use gt cam parameters")
+    trans_mat = synth.GT_TRANS_MAT                     # reference demo/demo.py:272-276
+    sdf_params = (-1, -1, -1, 1, 1, 1)                 # reference demo/demo.py:278
+    t0 = time.time()
+    gfeat, feats = enc(img)
+    if world > 1 and rank != 0:
+        feats, gfeat = [torch.zeros_like(f) for f in feats], torch.zeros_like(gfeat)
+    pipe = MeshPipeline(ctx, rank, world, dist)
+    iso = FLAGS.iso
+    if iso is None:
+        pipe.run(feats, gfeat, trans_mat, FLAGS.sdf_res, want_mesh=False)
+        t = torch.tensor([median_iso(pipe.last_sdf)], device=ctx.device)
+        if world > 1:
+            dist.broadcast(t, src=0)
+        iso = float(t.item())
+        log("demo: --iso not given, using the grid median %.6g (random weights have no zero level set)" % iso)
+    torch.cuda.synchronize()
+    t1 = time.time()
+    verts, tris = pipe.run(feats, gfeat, trans_mat, FLAGS.sdf_res, iso, sdf_params)
+    torch.cuda.synchronize()
+    t2 = time.time()
+    if rank == 0:
+        os.makedirs(os.path.dirname(os.path.abspath(FLAGS.out)), exist_ok=True)
+        api.write_obj(FLAGS.out, verts.cpu().numpy(), tris.cpu().numpy())
+        log("demo: encoder %.1f ms, grid+mesh %.1f ms (%d^3 points, %d GPU(s)), %d vertices / %d faces -> %s"
+            % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, FLAGS.sdf_res + 1, world, verts.shape[0], tris.shape[0], FLAGS.out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
