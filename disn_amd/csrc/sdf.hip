@@ -24,6 +24,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -237,95 +238,154 @@ struct DecodeArgs {
 };
 
 // ---- weight pipeline: global -> LDS ring by LDS-DMA, shared by the 4 waves ----
+// The fragment stream is consumed in stages of 16 pairs (32 KiB).  Four ring
+// slots; while stage g is being multiplied, g+1 is already in LDS, g+2 is in
+// flight and g+3 is being issued.  The only rendezvous is in the MIDDLE of a
+// stage (after pair 7): every wave waits for its own part of stage g+1
+// (counted vmcnt), all meet at one s_barrier, and the slot of stage g-1, which
+// every wave has left by then, is refilled -- one 1 KiB LDS-DMA per wave after
+// each of pairs 8..15.  Fragment reads run three pairs ahead of their MFMAs
+// and cross stage boundaries, so a stage start costs nothing.
 constexpr int STAGE_PAIRS = 16;                          // fragment pairs per stage
 constexpr int STAGE_BYTES = STAGE_PAIRS * 2048;          // 32 KiB
-constexpr int NSLOT = 4;                                 // ring slots (3 stages in flight)
-constexpr int PF = 2;                                    // fragment pairs read ahead of the MFMA triple that uses them
+constexpr int NSLOT = 4;                                 // ring slots
 constexpr int STAGES_PER_STREAM = PAIRS / STAGE_PAIRS;   // 66
 constexpr int STAGES_PER_TILE = 2 * STAGES_PER_STREAM;   // 132
 constexpr int SP_LDS_FLOATS = 2 * SP_SIZE;
 constexpr int LDS_BYTES = NSLOT * STAGE_BYTES + SP_LDS_FLOATS * 4;
 static_assert(PAIRS % STAGE_PAIRS == 0, "stream must be a whole number of stages");
 
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-struct Pipe {
-  const char* ws;      // global fragment stream (STAGES_PER_TILE stages, then it repeats)
-  char* ring;          // LDS ring base
-  int g;               // next stage to consume (counts across tiles)
-  int total;           // stages this workgroup will consume in all
-  int wave, lane;
+struct Frags {
+  bf16x8 hi[4], lo[4];   // register ring: pair p lives in slot p & 3
+};
 
-  // each wave copies a quarter of the stage: 8 x 1 KiB wave-instructions
-  __device__ __forceinline__ void issue(int stage) const {
-    const char* src = ws + (size_t)(stage % STAGES_PER_TILE) * STAGE_BYTES + wave * (STAGE_BYTES / 4) + lane * 16;
-    char* dst = ring + (stage % NSLOT) * STAGE_BYTES + wave * (STAGE_BYTES / 4);
-    const unsigned dst32 = (unsigned)(size_t)(lds_ptr_t)dst;   // wave-uniform LDS byte address
-#pragma unroll
-    for (int i = 0; i < STAGE_BYTES / 4 / 1024; ++i) {
-      // LDS-DMA in asm so that hipcc does not count it: its own bookkeeping would drain
-      // vmcnt(0) before every ds_read.  M0 (LDS base) is set and restored in the same statement.
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src + i * 1024), "s"(dst32 + i * 1024) : "memory");
-    }
+struct Pipe {
+  const char* ws;        // global fragment stream (STAGES_PER_TILE stages, then it repeats)
+  char* ring;            // LDS ring base
+  unsigned ring32;       // its LDS byte address
+  int g;                 // stage being consumed (counts across tiles)
+  int total;             // stages this workgroup will consume in all
+  int wave, lane;
+  const uint4* cur;      // this lane's view of stage g / g+1 in LDS
+  const uint4* nxt;
+  const char* dma_src;   // this lane's source of the stage being issued (g+3)
+  unsigned dma_dst;      // its LDS destination for this wave
+  bool dma_on;
+
+  __device__ __forceinline__ const uint4* slot_ptr(int stage) const {
+    return (const uint4*)(ring + (stage & (NSLOT - 1)) * STAGE_BYTES) + lane;
   }
-  // wait for stage g (own DMA), rendezvous, refill the slot everyone has just left
-  __device__ __forceinline__ const uint4* acquire() {
-    const int ahead = total - 1 - g;   // stages already issued beyond g: min(ahead, 2)
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __device__ __forceinline__ void dma_setup(int stage) {
+    dma_src = ws + (size_t)(stage % STAGES_PER_TILE) * STAGE_BYTES + wave * (STAGE_BYTES / 4) + lane * 16;
+    dma_dst = ring32 + (stage & (NSLOT - 1)) * STAGE_BYTES + wave * (STAGE_BYTES / 4);
+  }
+  // one 1 KiB piece (the instruction offset advances the global AND the LDS address):
+  // asm LDS-DMA so that hipcc does not count it (its own bookkeeping
+  // would drain vmcnt(0) before every ds_read); M0 is set and restored in the statement
+  template <int I>
+  __device__ __forceinline__ void dma_piece() const {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%4\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(dma_src + (I >= 4 ? 4096 : 0)), "s"(dma_dst), "i"(I >= 4 ? 4096 : 0), "i"((I & 3) * 1024)
+                 : "memory");
+  }
+  __device__ __forceinline__ void dma_all() const {
+    dma_piece<0>(); dma_piece<1>(); dma_piece<2>(); dma_piece<3>();
+    dma_piece<4>(); dma_piece<5>(); dma_piece<6>(); dma_piece<7>();
+  }
+  // middle of stage g: stage g+1 must be in LDS for everyone; slot of g-1 is free afterwards
+  __device__ __forceinline__ void mid_sync() {
+    if (g + 2 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (g + 3 < total) issue(g + 3);
-    const uint4* slot = (const uint4*)(ring + (g % NSLOT) * STAGE_BYTES);
+    dma_on = g + 3 < total;
+    dma_setup(g + 3);
+  }
+  __device__ __forceinline__ void advance() {
     ++g;
-    return slot;
+    cur = nxt;
+    nxt = slot_ptr(g + 1);
   }
 };
 
-// MFMA triples in VGPR-accumulator and AGPR-accumulator form.  Inline asm so the
+// single MFMAs in VGPR-accumulator and AGPR-accumulator form.  Inline asm so the
 // accumulator file of each chain is ours to choose (the 512-wide fold2/conv1
 // block owns all 256 AGPRs, everything else accumulates in VGPRs).  Hazards the
 // compiler does not pad for an asm statement: a VALU-written operand needs two
-// wait states before the MFMA reads it (leading s_nop 1); the result needs the
-// drain below before any non-MFMA reader.
-__device__ __forceinline__ void mma3_v(floatx16& acc, bf16x8 whi, bf16x8 wlo, bf16x8 xhi, bf16x8 xlo) {
-  asm("s_nop 1\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %1, %4, %0\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %1, %3, %0"
-      : "+v"(acc) : "v"(whi), "v"(wlo), "v"(xhi), "v"(xlo));
-}
-__device__ __forceinline__ void mma3_a(floatx16& acc, bf16x8 whi, bf16x8 wlo, bf16x8 xhi, bf16x8 xlo) {
-  asm("s_nop 1\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %1, %4, %0\n\t"
-      "v_mfma_f32_32x32x16_bf16 %0, %1, %3, %0"
-      : "+a"(acc) : "v"(whi), "v"(wlo), "v"(xhi), "v"(xlo));
+// wait states before the MFMA reads it (s_nop 1 on the first MFMA of a pair, the
+// only one that can follow VALU code); a result needs the drain below before
+// any non-MFMA reader.
+template <bool AGPR, bool LEAD>
+__device__ __forceinline__ void mfma1(floatx16& acc, const bf16x8& a, const bf16x8& b) {
+  if constexpr (AGPR) {
+    if constexpr (LEAD) asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  } else {
+    if constexpr (LEAD) asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  }
 }
 // 8-pass MFMA result -> any other reader: 12+ wait states
 __device__ __forceinline__ void drain_v(floatx16& acc) { asm("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
 __device__ __forceinline__ void drain_a(floatx16& acc) { asm("s_nop 15\n\ts_nop 3" : "+a"(acc)); }
 
-__device__ __forceinline__ void frag_pair(const uint4* slot, int pair, int lane, bf16x8& hi, bf16x8& lo) {
-  const uint4* p = slot + pair * 128 + lane;
-  hi = as_bf16x8(p[0]);
-  lo = as_bf16x8(p[64]);
+// pair P of the current stage: w_lo*x_hi + w_hi*x_lo + w_hi*x_hi into acc, with the
+// fragment reads of pair P+3 (possibly in the next stage), the pipeline's
+// rendezvous / refill and the caller's filler work slotted between the MFMAs
+template <int P, bool AGPR, class Extra>
+__device__ __forceinline__ void pair_step(Pipe& pipe, Frags& fr, floatx16& acc, const bf16x8& xhi, const bf16x8& xlo,
+                                          Extra extra) {
+  constexpr int c = P & 3, n = (P + 3) & 3;
+  const uint4* src = (P + 3 < STAGE_PAIRS) ? pipe.cur + (P + 3) * 128 : pipe.nxt + (P + 3 - STAGE_PAIRS) * 128;
+  mfma1<AGPR, true>(acc, fr.lo[c], xhi);
+  SCHED_FENCE();
+  fr.hi[n] = as_bf16x8(src[0]);
+  SCHED_FENCE();
+  mfma1<AGPR, false>(acc, fr.hi[c], xlo);
+  SCHED_FENCE();
+  fr.lo[n] = as_bf16x8(src[64]);
+  SCHED_FENCE();
+  mfma1<AGPR, false>(acc, fr.hi[c], xhi);
+  SCHED_FENCE();
+  if constexpr (P == 7) pipe.mid_sync();
+  if constexpr (P >= 8) {
+    if (pipe.dma_on) pipe.template dma_piece<P - 8>();
+  }
+  extra();
+  SCHED_FENCE();
+  if constexpr (P == STAGE_PAIRS - 1) pipe.advance();
 }
 
-// ReLU + bf16 hi/lo split of accumulator registers 8s..8s+7 -> B fragment of k-step s
-__device__ __forceinline__ void relu_split(const floatx16& acc, int s, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float v = fmaxf(acc[8 * s + j], 0.0f);
-    __bf16 hb = (__bf16)v;
-    hi[j] = hb;
-    lo[j] = (__bf16)(v - (float)hb);
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
   }
+}
+
+__device__ __forceinline__ float relu1(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));   // one op (fmaxf adds a canonicalize)
+  return r;
+}
+// ReLU + bf16 hi/lo split of accumulator elements e, e+1 (e even) into the two B fragments
+__device__ __forceinline__ void cvt_pair(const floatx16& acc, int e, bf16x8 (&hi)[2], bf16x8 (&lo)[2]) {
+  float v0 = relu1(acc[e]), v1 = relu1(acc[e + 1]);
+  __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+  hi[e >> 3][e & 7] = h0;
+  hi[e >> 3][(e & 7) + 1] = h1;
+  lo[e >> 3][e & 7] = (__bf16)(v0 - (float)h0);
+  lo[e >> 3][(e & 7) + 1] = (__bf16)(v1 - (float)h1);
 }
 
 // accumulator initialised with a per-feature vector: reg g <-> feature base + (g&3) + 8(g>>2) + 4h
@@ -339,10 +399,19 @@ __device__ __forceinline__ floatx16 bias_init(const float* b, int base, int h) {
   return acc;
 }
 
+// one stage of fold1/conv3: 16 k-steps over the resident h2 fragments into one 32-feature block
+__device__ __forceinline__ void l3_stage(Pipe& pipe, Frags& fr, floatx16& acc3, const bf16x8 (&h2hi)[16],
+                                         const bf16x8 (&h2lo)[16]) {
+  static_for<16>([&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+    pair_step<P, false>(pipe, fr, acc3, h2hi[P], h2lo[P], [] {});
+  });
+}
+
 // one decoder stream for the wave's 32 points; sp = this stream's parameters in LDS
 template <bool LOCAL>
-__device__ float stream_pass(Pipe& pipe, const float* sp, const float* __restrict__ pmap, float px, float py, float pz,
-                             const Corners& cn) {
+__device__ float stream_pass(Pipe& pipe, Frags& fr, const float* sp, const float* __restrict__ pmap, float px, float py,
+                             float pz, float u, float v) {
   const int lane = pipe.lane, h = lane >> 5;
   // fold1/conv1 (3 -> 64) on the VALU, written straight into B-fragment order
   bf16x8 h1hi[4], h1lo[4];
@@ -352,34 +421,40 @@ __device__ float stream_pass(Pipe& pipe, const float* sp, const float* __restric
     for (int j = 0; j < 8; ++j) {
       int f = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
       floatx4 w = *(const floatx4*)(sp + SP_W1 + 4 * f);
-      float v = fmaf(pz, w[2], fmaf(py, w[1], px * w[0])) + w[3];
-      v = fmaxf(v, 0.0f);
-      __bf16 hb = (__bf16)v;
+      float t = fmaf(pz, w[2], fmaf(py, w[1], px * w[0])) + w[3];
+      t = fmaxf(t, 0.0f);
+      __bf16 hb = (__bf16)t;
       h1hi[ks][j] = hb;
-      h1lo[ks][j] = (__bf16)(v - (float)hb);
+      h1lo[ks][j] = (__bf16)(t - (float)hb);
     }
   }
   // fold1/conv2 (64 -> 256): 2 stages of 4 blocks; all of h2 stays resident as B fragments
   bf16x8 h2hi[16], h2lo[16];
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
-    const uint4* slot = pipe.acquire();
+    floatx16 acc2[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc2[b] = bias_init(sp + SP_B2, 32 * (4 * st + b), h);
+    static_for<16>([&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      constexpr int b = P >> 2, ks = P & 3;
+      pair_step<P, false>(pipe, fr, acc2[b], h1hi[ks], h1lo[ks], [] {});
+    });
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int nb2 = 4 * st + b;
-      floatx16 acc2 = bias_init(sp + SP_B2, 32 * nb2, h);
-      bf16x8 whi[4], wlo[4];
+      drain_v(acc2[b]);
+      bf16x8 thi[2], tlo[2];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) frag_pair(slot, 4 * b + ks, lane, whi[ks], wlo[ks]);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) mma3_v(acc2, whi[ks], wlo[ks], h1hi[ks], h1lo[ks]);
-      drain_v(acc2);
-      relu_split(acc2, 0, h2hi[2 * nb2], h2lo[2 * nb2]);
-      relu_split(acc2, 1, h2hi[2 * nb2 + 1], h2lo[2 * nb2 + 1]);
+      for (int e = 0; e < 16; e += 2) cvt_pair(acc2[b], e, thi, tlo);
+      h2hi[2 * nb2] = thi[0]; h2hi[2 * nb2 + 1] = thi[1];
+      h2lo[2 * nb2] = tlo[0]; h2lo[2 * nb2 + 1] = tlo[1];
     }
   }
   // fold2/conv1 accumulators (point part, 512 wide): bias (+ image term) first
   floatx16 acc4[16];
+  Corners cn;
+  if (LOCAL) cn = corners(u, v);
 #pragma unroll
   for (int nb4 = 0; nb4 < 16; ++nb4) {
     acc4[nb4] = bias_init(sp + SP_B4, 32 * nb4, h);
@@ -388,68 +463,79 @@ __device__ float stream_pass(Pipe& pipe, const float* sp, const float* __restric
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float* src = pmap + (size_t)cn.pix[c] * 512 + 32 * nb4 + 4 * h;
+        asm volatile("" : "+v"(src));   // keep hipcc from hoisting the gather above the previous stream
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          floatx4 v = *(const floatx4*)(src + 8 * q);
+          floatx4 t = *(const floatx4*)(src + 8 * q);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc4[nb4][4 * q + e] = fmaf(cn.w[c], v[e], acc4[nb4][4 * q + e]);
+          for (int e = 0; e < 4; ++e) acc4[nb4][4 * q + e] = fmaf(cn.w[c], t[e], acc4[nb4][4 * q + e]);
         }
       }
     }
+    asm volatile("" : "+a"(acc4[nb4]));   // park the block in the accumulator file now, not at its first MFMA
   }
   // fold1/conv3 (256 -> 512) chained into fold2/conv1: each finished 32-feature
-  // block of h3 is consumed at once as two k-steps of all sixteen accumulators
-#pragma unroll 1
-  for (int nb3 = 0; nb3 < 16; ++nb3) {
-    floatx16 acc3 = bias_init(sp + SP_B3, 32 * nb3, h);
-    const uint4* slot = pipe.acquire();
-    {
-      bf16x8 whi[PF + 1], wlo[PF + 1];
-#pragma unroll
-      for (int ks = 0; ks < PF; ++ks) frag_pair(slot, ks, lane, whi[ks], wlo[ks]);
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        if (ks + PF < 16) frag_pair(slot, ks + PF, lane, whi[(ks + PF) % (PF + 1)], wlo[(ks + PF) % (PF + 1)]);
-        mma3_v(acc3, whi[ks % (PF + 1)], wlo[ks % (PF + 1)], h2hi[ks], h2lo[ks]);
-      }
-    }
+  // block of h3 is consumed at once as two k-steps of all sixteen accumulators.
+  // Software-pipelined by one block: while block nb3 feeds fold2/conv1 (two
+  // stages), block nb3+1 has already been accumulated (one stage) and its
+  // ReLU + hi/lo split fills the gaps between the fold2/conv1 MFMAs.
+  bf16x8 xhi[2], xlo[2];
+  {
+    floatx16 acc3 = bias_init(sp + SP_B3, 0, h);
+    l3_stage(pipe, fr, acc3, h2hi, h2lo);
     drain_v(acc3);
-    bf16x8 xhi[2], xlo[2];
-    relu_split(acc3, 0, xhi[0], xlo[0]);
-    relu_split(acc3, 1, xhi[1], xlo[1]);
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      slot = pipe.acquire();
-      bf16x8 whi[PF + 1], wlo[PF + 1];
-#pragma unroll
-      for (int t = 0; t < PF; ++t) frag_pair(slot, t, lane, whi[t], wlo[t]);
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        if (t + PF < 16) frag_pair(slot, t + PF, lane, whi[(t + PF) % (PF + 1)], wlo[(t + PF) % (PF + 1)]);
-        mma3_a(acc4[8 * st + (t >> 1)], whi[t % (PF + 1)], wlo[t % (PF + 1)], xhi[t & 1], xlo[t & 1]);
-      }
-    }
+    for (int e = 0; e < 16; e += 2) cvt_pair(acc3, e, xhi, xlo);
   }
-  // fold2/conv2 (512 -> 256), consuming the fold2/conv1 accumulators block by block
+#pragma unroll 1
+  for (int nb3 = 0; nb3 < 15; ++nb3) {
+    floatx16 acc3n = bias_init(sp + SP_B3, 32 * (nb3 + 1), h);
+    l3_stage(pipe, fr, acc3n, h2hi, h2lo);
+    bf16x8 nhi[2], nlo[2];
+    static_for<16>([&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      pair_step<P, true>(pipe, fr, acc4[P >> 1], xhi[P & 1], xlo[P & 1], [&] {
+        if constexpr (P == 1) drain_v(acc3n);
+        if constexpr (P >= 2 && P < 10) cvt_pair(acc3n, 2 * (P - 2), nhi, nlo);
+      });
+    });
+    static_for<16>([&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      pair_step<P, true>(pipe, fr, acc4[8 + (P >> 1)], xhi[P & 1], xlo[P & 1], [] {});
+    });
+    xhi[0] = nhi[0]; xhi[1] = nhi[1]; xlo[0] = nlo[0]; xlo[1] = nlo[1];
+  }
+  // last block: nothing left to convert
+  static_for<16>([&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+    pair_step<P, true>(pipe, fr, acc4[P >> 1], xhi[P & 1], xlo[P & 1], [] {});
+  });
+  static_for<16>([&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+    pair_step<P, true>(pipe, fr, acc4[8 + (P >> 1)], xhi[P & 1], xlo[P & 1], [] {});
+  });
+  // fold2/conv2 (512 -> 256), consuming the fold2/conv1 accumulators block by block;
+  // the split of block nb4+1 fills the gaps between the MFMAs of block nb4
   floatx16 acc5[8];
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) acc5[nb] = bias_init(sp + SP_B5, 32 * nb, h);
+  bf16x8 yhi[2][2], ylo[2][2];
+  drain_a(acc4[0]);
 #pragma unroll
-  for (int nb4 = 0; nb4 < 16; ++nb4) {
-    drain_a(acc4[nb4]);
-    bf16x8 xhi[2], xlo[2];
-    relu_split(acc4[nb4], 0, xhi[0], xlo[0]);
-    relu_split(acc4[nb4], 1, xhi[1], xlo[1]);
-    const uint4* slot = pipe.acquire();
-    bf16x8 whi[PF + 1], wlo[PF + 1];
-#pragma unroll
-    for (int t = 0; t < PF; ++t) frag_pair(slot, t, lane, whi[t], wlo[t]);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      if (t + PF < 16) frag_pair(slot, t + PF, lane, whi[(t + PF) % (PF + 1)], wlo[(t + PF) % (PF + 1)]);
-      mma3_v(acc5[t >> 1], whi[t % (PF + 1)], wlo[t % (PF + 1)], xhi[t & 1], xlo[t & 1]);
-    }
-  }
+  for (int e = 0; e < 16; e += 2) cvt_pair(acc4[0], e, yhi[0], ylo[0]);
+  static_for<16>([&](auto nc) {
+    constexpr int nb4 = decltype(nc)::value;
+    constexpr int cur = nb4 & 1, nx = cur ^ 1, nn = nb4 < 15 ? nb4 + 1 : 15;
+    static_for<16>([&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      pair_step<P, false>(pipe, fr, acc5[P >> 1], yhi[cur][P & 1], ylo[cur][P & 1], [&] {
+        if constexpr (nb4 < 15) {
+          if constexpr (P == 1) drain_a(acc4[nn]);
+          if constexpr (P >= 2 && P < 10) cvt_pair(acc4[nn], 2 * (P - 2), yhi[nx], ylo[nx]);
+        }
+      });
+    });
+  });
   // fold2/conv5 (256 -> 1): this lane holds half of its point's features
   float part = 0.0f;
 #pragma unroll
@@ -471,19 +557,32 @@ __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float* sp_lds = (float*)(lds + NSLOT * STAGE_BYTES);
   for (int i = threadIdx.x; i < SP_LDS_FLOATS; i += 256) sp_lds[i] = a.sp[i];
+  __syncthreads();
   const long long ntiles = (a.n + 127) / 128;
   const long long mine = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;   // >= 1: grid <= ntiles
   Pipe pipe;
   pipe.ws = (const char*)a.ws;
   pipe.ring = lds;
+  pipe.ring32 = (unsigned)(size_t)(lds_ptr_t)lds;
   pipe.g = 0;
-  pipe.total = (int)(mine * STAGES_PER_TILE);
+  pipe.total = (int)(mine * STAGES_PER_TILE);   // >= 132
   pipe.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   pipe.lane = threadIdx.x & 63;
-  pipe.issue(0);
-  pipe.issue(1);
-  pipe.issue(2);
-  __syncthreads();   // sp_lds visible (plain barrier: drains the three stages once, harmless)
+  pipe.dma_setup(0); pipe.dma_all();
+  pipe.dma_setup(1); pipe.dma_all();
+  pipe.dma_setup(2); pipe.dma_all();
+  pipe.dma_on = false;
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  pipe.cur = pipe.slot_ptr(0);
+  pipe.nxt = pipe.slot_ptr(1);
+  Frags fr;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    fr.hi[t] = as_bf16x8(pipe.cur[t * 128]);
+    fr.lo[t] = as_bf16x8(pipe.cur[t * 128 + 64]);
+  }
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     long long p = tile * 128 + pipe.wave * 32 + (pipe.lane & 31);
     const bool valid = p < a.n;
@@ -506,9 +605,8 @@ __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
     }
     float u, v;
     project(a.T, x, y, z, u, v);
-    const Corners cn = corners(u, v);
-    float g = stream_pass<false>(pipe, sp_lds, a.pmap, xr, yr, zr, cn);
-    float l = stream_pass<true>(pipe, sp_lds + SP_SIZE, a.pmap, xr, yr, zr, cn);
+    float g = stream_pass<false>(pipe, fr, sp_lds, a.pmap, xr, yr, zr, u, v);
+    float l = stream_pass<true>(pipe, fr, sp_lds + SP_SIZE, a.pmap, xr, yr, zr, u, v);
     float pred = __fadd_rn(g, l);   // reference models/model_normalization.py:204
     if (valid && pipe.lane < 32) a.out[p] = a.scale_out ? (float)((double)pred / 10.0) : pred;
   }
@@ -600,8 +698,11 @@ extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
     frag.reserve((size_t)PAIRS * 1024);
     for (int nb2 = 0; nb2 < 8; ++nb2)
       for (int ks = 0; ks < 4; ++ks) pack_pair(frag, q.w2, 256, nb2, ks);
+    // fold1/conv3 runs one block ahead of fold2/conv1 (software pipeline in stream_pass)
+    for (int ks = 0; ks < 16; ++ks) pack_pair(frag, q.w3, 512, 0, ks);
     for (int nb3 = 0; nb3 < 16; ++nb3) {
-      for (int ks = 0; ks < 16; ++ks) pack_pair(frag, q.w3, 512, nb3, ks);
+      if (nb3 < 15)
+        for (int ks = 0; ks < 16; ++ks) pack_pair(frag, q.w3, 512, nb3 + 1, ks);
       for (int nb4 = 0; nb4 < 16; ++nb4)
         for (int sft = 0; sft < 2; ++sft) pack_pair(frag, q.w4, 512, nb4, 2 * nb3 + sft);  // rows 0..511 = point features
     }
