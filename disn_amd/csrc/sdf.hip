@@ -413,6 +413,32 @@ template <bool LOCAL>
 __device__ float stream_pass(Pipe& pipe, Frags& fr, const float* sp, const float* __restrict__ pmap, float px, float py,
                              float pz, float u, float v) {
   const int lane = pipe.lane, h = lane >> 5;
+  // fold2/conv1 accumulators (point part, 512 wide): bias (+ image term) first, while the
+  // register file is still nearly empty so that many gather loads can be in flight
+  floatx16 acc4[16];
+  Corners cn;
+  if (LOCAL) {
+    asm volatile("" : "+v"(u), "+v"(v));   // keep hipcc from hoisting the gather above the previous stream
+    cn = corners(u, v);
+  }
+#pragma unroll
+  for (int nb4 = 0; nb4 < 16; ++nb4) {
+    acc4[nb4] = bias_init(sp + SP_B4, 32 * nb4, h);
+    if (LOCAL) {
+      // image part of fold2/conv1: bilinear blend of the pre-projected map
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float* src = pmap + (size_t)cn.pix[c] * 512 + 32 * nb4 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          floatx4 t = *(const floatx4*)(src + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc4[nb4][4 * q + e] = fmaf(cn.w[c], t[e], acc4[nb4][4 * q + e]);
+        }
+      }
+    }
+    asm volatile("" : "+a"(acc4[nb4]));   // park the block in the accumulator file now, not at its first MFMA
+  }
   // fold1/conv1 (3 -> 64) on the VALU, written straight into B-fragment order
   bf16x8 h1hi[4], h1lo[4];
 #pragma unroll
@@ -450,29 +476,6 @@ __device__ float stream_pass(Pipe& pipe, Frags& fr, const float* sp, const float
       h2hi[2 * nb2] = thi[0]; h2hi[2 * nb2 + 1] = thi[1];
       h2lo[2 * nb2] = tlo[0]; h2lo[2 * nb2 + 1] = tlo[1];
     }
-  }
-  // fold2/conv1 accumulators (point part, 512 wide): bias (+ image term) first
-  floatx16 acc4[16];
-  Corners cn;
-  if (LOCAL) cn = corners(u, v);
-#pragma unroll
-  for (int nb4 = 0; nb4 < 16; ++nb4) {
-    acc4[nb4] = bias_init(sp + SP_B4, 32 * nb4, h);
-    if (LOCAL) {
-      // image part of fold2/conv1: bilinear blend of the pre-projected map
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float* src = pmap + (size_t)cn.pix[c] * 512 + 32 * nb4 + 4 * h;
-        asm volatile("" : "+v"(src));   // keep hipcc from hoisting the gather above the previous stream
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          floatx4 t = *(const floatx4*)(src + 8 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc4[nb4][4 * q + e] = fmaf(cn.w[c], t[e], acc4[nb4][4 * q + e]);
-        }
-      }
-    }
-    asm volatile("" : "+a"(acc4[nb4]));   // park the block in the accumulator file now, not at its first MFMA
   }
   // fold1/conv3 (256 -> 512) chained into fold2/conv1: each finished 32-feature
   // block of h3 is consumed at once as two k-steps of all sixteen accumulators.
