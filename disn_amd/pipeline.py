@@ -14,10 +14,44 @@ import torch
 from .slabs import slab_bases, slab_ranges
 
 
+class _Comm:
+    """torch.distributed with device tensors.  Backend "nccl" (RCCL) moves them directly; with
+    "gloo" (CPU rehearsals and tests: several ranks on one GPU) they are staged through the host."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.host = dist is not None and dist.get_backend() == "gloo"
+
+    def broadcast(self, t, src):
+        if not self.host:
+            return self.dist.broadcast(t, src=src)
+        c = t.cpu()
+        self.dist.broadcast(c, src=src)
+        t.copy_(c)
+
+    def all_gather(self, out_list, t):
+        if not self.host:
+            return self.dist.all_gather(out_list, t)
+        outs = [torch.empty_like(t, device="cpu") for _ in out_list]
+        self.dist.all_gather(outs, t.cpu())
+        for o, c in zip(out_list, outs):
+            o.copy_(c)
+
+    def send(self, t, dst):
+        self.dist.send(t.cpu() if self.host else t, dst=dst)
+
+    def recv(self, t, src):
+        if not self.host:
+            return self.dist.recv(t, src=src)
+        c = torch.empty_like(t, device="cpu")
+        self.dist.recv(c, src=src)
+        t.copy_(c)
+
+
 class MeshPipeline:
     def __init__(self, ctx, rank=0, world=1, dist=None):
         self.ctx, self.rank, self.world = ctx, rank, world
-        self.dist = dist            # the torch.distributed module when world > 1
+        self.dist = _Comm(dist) if world > 1 else None   # torch.distributed when world > 1
         self.decode_events = []     # (start, end) torch events around the decoder launch
         self.time_decode = False
         self.last_sdf = None

@@ -59,7 +59,9 @@ def stitch_slabs(ctx, counts, outs):
     verts = np.concatenate(centres_v + edges_v)
     keys = np.concatenate(centres_k + edges_k)
     tris = np.concatenate([o[1] for o in outs]).astype(np.int32)
-    if len(tris):
+    if len(tris) and ctx is None:      # host-only stitch (CPU tests)
+        tris = tris[np.lexsort((tris[:, 2], tris[:, 1], tris[:, 0]))]
+    elif len(tris):
         t = torch.from_numpy(np.ascontiguousarray(tris)).to(ctx.device)
         ctx.sort_triangles(t, max(len(verts), 1))
         torch.cuda.synchronize()

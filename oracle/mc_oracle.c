@@ -36,6 +36,7 @@ typedef struct {
   int32_t* tris;  /* n_tri x 3, 0-based */
   int64_t* keys;  /* per vertex: signed key (B.4/B.5) */
   int64_t n_bad;  /* voxels whose ambiguity lookup was -1 (B.3) */
+  int32_t* tri_layer; /* per triangle: k of the voxel that emitted it (slab tests) */
 } McResult;
 
 /* B.3 faceTest */
@@ -89,7 +90,7 @@ static int tri_cmp(const void* a, const void* b) {
 
 void mc_oracle_free(McResult* r) {
   if (!r) return;
-  free(r->verts); free(r->tris); free(r->keys); free(r);
+  free(r->verts); free(r->tris); free(r->keys); free(r->tri_layer); free(r);
 }
 
 /* val[k][j][i], x fastest (reference: demo/demo.py:342-353 .dist layout).
@@ -155,7 +156,9 @@ McResult* mc_oracle_run(const float* val, int nx, int ny, int nz, const double* 
   r->verts = (double*)malloc(sizeof(double) * 3 * (nv ? nv : 1));
   r->keys = (int64_t*)malloc(sizeof(int64_t) * (nv ? nv : 1));
   r->tris = (int32_t*)malloc(sizeof(int32_t) * 3 * (n_tri ? n_tri : 1));
-  if (!r->verts || !r->keys || !r->tris) return NULL;
+  int32_t* tl = (int32_t*)malloc(sizeof(int32_t) * 4 * (n_tri ? n_tri : 1));   /* (a,b,c,layer) rows, sorted together */
+  r->tri_layer = (int32_t*)malloc(sizeof(int32_t) * (n_tri ? n_tri : 1));
+  if (!r->verts || !r->keys || !r->tris || !tl || !r->tri_layer) return NULL;
 
   /* B.4 positions; B.6: edge vertices follow the centre vertices, ascending key */
 #pragma omp parallel for
@@ -232,14 +235,20 @@ McResult* mc_oracle_run(const float* val, int nx, int ny, int nz, const double* 
         int m = 0;
         if (v[1] < v[m]) m = 1;
         if (v[2] < v[m]) m = 2;
-        r->tris[3 * ti + 0] = v[m];
-        r->tris[3 * ti + 1] = v[(m + 1) % 3];
-        r->tris[3 * ti + 2] = v[(m + 2) % 3];
+        tl[4 * ti + 0] = v[m];
+        tl[4 * ti + 1] = v[(m + 1) % 3];
+        tl[4 * ti + 2] = v[(m + 2) % 3];
+        tl[4 * ti + 3] = (int32_t)(p / sxy);
         ++ti;
       }
     }
     free(cmap);
-    qsort(r->tris, (size_t)n_tri, 3 * sizeof(int32_t), tri_cmp);
+    qsort(tl, (size_t)n_tri, 4 * sizeof(int32_t), tri_cmp);   /* stable enough: ties are identical triples */
+    for (int64_t t = 0; t < n_tri; ++t) {
+      memcpy(&r->tris[3 * t], &tl[4 * t], 3 * sizeof(int32_t));
+      r->tri_layer[t] = tl[4 * t + 3];
+    }
+    free(tl);
   }
   free(c); free(sub); free(eflag); free(ebase);
   return r;
@@ -250,6 +259,7 @@ int64_t mc_oracle_n_centre(const McResult* r) { return r->n_centre; }
 int64_t mc_oracle_n_edge(const McResult* r) { return r->n_edge; }
 int64_t mc_oracle_n_tri(const McResult* r) { return r->n_tri; }
 int64_t mc_oracle_n_bad(const McResult* r) { return r->n_bad; }
+void mc_oracle_copy_layers(const McResult* r, int32_t* layers) { memcpy(layers, r->tri_layer, sizeof(int32_t) * r->n_tri); }
 void mc_oracle_copy(const McResult* r, double* verts, int32_t* tris, int64_t* keys) {
   int64_t nv = r->n_centre + r->n_edge;
   if (verts) memcpy(verts, r->verts, sizeof(double) * 3 * nv);
