@@ -141,6 +141,15 @@ def main():
                          "kernel_ms": dec_ms, "alg_flop_per_point": ALG_FLOP_PER_POINT,
                          "executed_mfma_tflops": mfma_tflops, "mfma_issue_frac": mfma_tflops / PEAK_BF16_TFLOPS},
         }
+        # HBM-side traffic of the dominant kernel, measured separately with rocprofv3 PMC passes
+        # (tools/pmc_decode.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md) and committed under profiles/
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if res == tr.get("sdf_res"):
+                out["roofline"]["traffic"] = tr["sdf_decode_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = tr["note"]
+        except (OSError, ValueError, KeyError):
+            pass
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(min(16, os.cpu_count() or 1))
             feats_np = [f.cpu().numpy() for f in feats]

@@ -11,7 +11,8 @@
 //                 vertices, already in the reference's key order
 //   mc_triangles  block scan of triangle/centre counts -> triangles with final
 //                 indices (smallest first) + centre vertices
-//   tri_sort_*    LSD radix sort (8-bit digits) -> lexicographic order
+//   tri_sort_*    LSD radix sort (8-bit digits: histogram, per-digit row scan,
+//                 stable scatter) -> lexicographic order
 // Algorithmic bytes: 4 B/grid point + 24 B/vertex + 12 B/triangle.
 // Compile with -ffp-contract=off: App. B specifies separately rounded
 // products; the arithmetic intrinsics below make that explicit as well.
@@ -414,36 +415,36 @@ __global__ __launch_bounds__(BLK) void tri_sort_hist(const int* __restrict__ tri
   hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];  // digit-major
 }
 
-// exclusive scan of hist[256*nb] in place (one workgroup)
-__global__ __launch_bounds__(1024) void tri_sort_scan(unsigned* __restrict__ hist, unsigned n) {
-  __shared__ unsigned part[1024];
-  const unsigned chunk = (n + 1023) / 1024;
-  const unsigned b0 = min(n, threadIdx.x * chunk), b1 = min(n, b0 + chunk);
-  unsigned s = 0;
-  for (unsigned b = b0; b < b1; ++b) s += hist[b];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    unsigned t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
-    __syncthreads();
-    part[threadIdx.x] += t;
-    __syncthreads();
+// one workgroup per digit: exclusive scan of that digit's row hist[d][0..nb) in place,
+// row sum to total[d]; the scatter kernel adds the 256-entry digit prefix itself
+__global__ __launch_bounds__(BLK) void tri_sort_rowscan(unsigned* __restrict__ hist, unsigned nb,
+                                                         unsigned* __restrict__ total) {
+  __shared__ unsigned lds[BLK / 64];
+  unsigned* row = hist + (size_t)blockIdx.x * nb;
+  unsigned carry = 0;
+  for (unsigned b0 = 0; b0 < nb; b0 += BLK) {
+    unsigned b = b0 + threadIdx.x;
+    unsigned v = b < nb ? row[b] : 0u, tot;
+    unsigned ex = block_excl_scan(v, lds, &tot);
+    if (b < nb) row[b] = carry + ex;
+    carry += tot;
   }
-  unsigned run = part[threadIdx.x] - s;
-  for (unsigned b = b0; b < b1; ++b) {
-    unsigned v = hist[b];
-    hist[b] = run;
-    run += v;
-  }
+  if (threadIdx.x == 0) total[blockIdx.x] = carry;
 }
 
 __global__ __launch_bounds__(BLK) void tri_sort_scatter(const int* __restrict__ in, int* __restrict__ out,
                                                          unsigned long long n, int comp, int shift,
-                                                         const unsigned* __restrict__ hist, unsigned nb) {
+                                                         const unsigned* __restrict__ hist, unsigned nb,
+                                                         const unsigned* __restrict__ total) {
   __shared__ unsigned basecnt[256];
   __shared__ unsigned wcnt[BLK / 64][256];
+  __shared__ unsigned sl[BLK / 64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  basecnt[threadIdx.x] = hist[(size_t)threadIdx.x * nb + blockIdx.x];
+  {
+    unsigned tot;   // digit prefix over the 256 row totals, then this block's offset inside the row
+    unsigned dig = block_excl_scan(total[threadIdx.x], sl, &tot);
+    basecnt[threadIdx.x] = dig + hist[(size_t)threadIdx.x * nb + blockIdx.x];
+  }
   unsigned long long base = (unsigned long long)blockIdx.x * SORT_TILE;
   for (int r = 0; r < SORT_ITEMS; ++r) {
 #pragma unroll
@@ -566,15 +567,15 @@ static int sort_tris(DisnCtx* ctx, McState* m, int* tris, uint64_t n, uint64_t m
   const int passes = (bits + 7) / 8;
   const unsigned nb = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
   DISN_TRY(disn_ensure(ctx, m->sort_tmp, n * 3 * sizeof(int)));
-  DISN_TRY(disn_ensure(ctx, m->sort_hist, (size_t)nb * 256 * sizeof(unsigned)));
+  DISN_TRY(disn_ensure(ctx, m->sort_hist, ((size_t)nb * 256 + 256) * sizeof(unsigned)));
   int* a = tris;
   int* b = (int*)m->sort_tmp.p;
   unsigned* hist = (unsigned*)m->sort_hist.p;
   for (int comp = 2; comp >= 0; --comp)
     for (int ps = 0; ps < passes; ++ps) {
       tri_sort_hist<<<nb, BLK, 0, stream>>>(a, n, comp, 8 * ps, hist, nb);
-      tri_sort_scan<<<1, 1024, 0, stream>>>(hist, nb * 256u);
-      tri_sort_scatter<<<nb, BLK, 0, stream>>>(a, b, n, comp, 8 * ps, hist, nb);
+      tri_sort_rowscan<<<256, BLK, 0, stream>>>(hist, nb, hist + (size_t)nb * 256);
+      tri_sort_scatter<<<nb, BLK, 0, stream>>>(a, b, n, comp, 8 * ps, hist, nb, hist + (size_t)nb * 256);
       int* t = a; a = b; b = t;
     }
   if (a != tris) DISN_HIP(ctx, hipMemcpyAsync(tris, a, n * 3 * sizeof(int), hipMemcpyDeviceToDevice, stream));
