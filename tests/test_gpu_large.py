@@ -1,0 +1,81 @@
+"""Full-size configurations (BASELINE.json configs[2], [4]): size-independent properties only --
+the CPU oracle would take minutes here.  sdf_res 512 through the whole pipeline (network grid
++ MC), sdf_res 1024 through marching cubes on an analytic field built on the device."""
+import numpy as np
+import pytest
+import torch
+
+import fields
+from oracle import net
+
+pytestmark = pytest.mark.gpu
+
+
+def _mesh_invariants(v, f, k, nc, closed=True):
+    # centre vertices first (descending k = ascending key), then edge vertices by ascending key (App. B.6);
+    # the two ranges are checked separately: centre keys of layer k=0 overlap the edge keys (App. B.8)
+    assert bool((np.diff(k[:nc]) > 0).all()) and bool((np.diff(k[nc:]) > 0).all())
+    assert bool((k[nc:] >= 0).all())
+    assert bool((f[:, 0] < f[:, 1]).all()) and bool((f[:, 0] < f[:, 2]).all())   # smallest index first
+    a, b = f[:-1], f[1:]
+    less = (a[:, 0] < b[:, 0]) | ((a[:, 0] == b[:, 0]) & ((a[:, 1] < b[:, 1]) | ((a[:, 1] == b[:, 1]) & (a[:, 2] < b[:, 2]))))
+    assert bool(less.all())                                          # strictly lexicographic, no duplicates
+    assert f.max() < len(v) and f.min() >= 0
+    if closed:
+        assert fields.mesh_is_closed_manifold(f)
+    else:
+        # surface may leave the box: every directed edge is unique (consistent orientation) and an
+        # edge without its reverse lies on the boundary of the box
+        t = f.astype(np.int64)
+        e = np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]])
+        n = int(t.max()) + 1
+        key, rkey = e[:, 0] * n + e[:, 1], e[:, 1] * n + e[:, 0]
+        u = np.unique(key)
+        assert len(u) == len(key)
+        open_e = e[~np.isin(key, rkey)]
+        on_wall = (np.abs(np.abs(v) - 1.0) < 1e-12).any(axis=1)
+        assert bool(on_wall[open_e[:, 0]].all()) and bool(on_wall[open_e[:, 1]].all())
+    assert bool(np.isfinite(v).all()) and float(np.abs(v).max()) <= 1.0 + 1e-9
+
+
+def test_res512_pipeline_invariants(ctx):
+    from disn_amd import synth
+    from disn_amd.pipeline import MeshPipeline, median_iso
+    maps, gf = net.synthetic_features(seed=6)
+    ctx.set_weights(synth.decoder_weights(seed=6))
+    feats = [torch.from_numpy(m).cuda() for m in maps]
+    g = torch.from_numpy(gf).cuda()
+    pipe = MeshPipeline(ctx)
+    pipe.run(feats, g, synth.GT_TRANS_MAT, 512, want_mesh=False)
+    sdf = pipe.last_sdf
+    assert sdf.shape == (513, 513, 513) and bool(torch.isfinite(sdf).all())
+    # every other plane of the 512 grid is a plane of the 256 grid (same points: linspace endpoints and midpoints are exact)
+    coarse = ctx.sdf_grid(synth.GT_TRANS_MAT, 256, z0=64, z1=64)
+    assert torch.equal(sdf[128, ::2, ::2], coarse[0])
+    iso = median_iso(sdf)
+    ctx.mc_count(sdf, iso)
+    v, f, k = ctx.mc_emit(want_keys=True)
+    torch.cuda.synchronize()
+    assert len(f) > 1_000_000
+    _mesh_invariants(v.cpu().numpy(), f.cpu().numpy(), k.cpu().numpy(), ctx._mc_counts[0], closed=False)
+
+
+def test_res1024_marching_cubes_invariants(ctx):
+    n = 1025
+    l = torch.linspace(-1, 1, n, device="cuda", dtype=torch.float64)
+    grid = torch.empty((n, n, n), dtype=torch.float32, device="cuda")
+    y, x = torch.meshgrid(l, l, indexing="ij")
+    for k0 in range(0, n, 64):                       # build the analytic field slab by slab on the device
+        z = l[k0:k0 + 64][:, None, None]
+        s1 = torch.sqrt((x - 0.2) ** 2 + y ** 2 + z ** 2) - 0.45
+        s2 = torch.sqrt((x + 0.3) ** 2 + (y - 0.1) ** 2 + (z + 0.2) ** 2) - 0.35
+        q = torch.sqrt(x * x + z * z) - 0.6
+        t = torch.sqrt(q * q + (y + 0.3) ** 2) - 0.12
+        grid[k0:k0 + 64] = torch.minimum(torch.minimum(s1, s2), t).float()
+    counts = ctx.mc_count(grid, 0.0)
+    v, f, k = ctx.mc_emit(want_keys=True)
+    torch.cuda.synchronize()
+    # the surface area is fixed, so counts scale ~4x per doubling: 143683 v / 287370 t at res 256 (reference tool)
+    assert abs(len(f) / (287370 * 16.0) - 1.0) < 0.01
+    assert (len(v) - len(f) // 2) % 2 == 0 and counts[2] == len(f)     # closed orientable surface: even Euler characteristic
+    _mesh_invariants(v.cpu().numpy(), f.cpu().numpy(), k.cpu().numpy(), counts[0])
