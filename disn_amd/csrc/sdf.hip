@@ -276,7 +276,6 @@ struct Pipe {
   const uint4* nxt;
   const char* dma_src;   // this lane's source of the stage being issued (g+3)
   unsigned dma_dst;      // its LDS destination for this wave
-  bool dma_on;
 
   __device__ __forceinline__ const uint4* slot_ptr(int stage) const {
     return (const uint4*)(ring + (stage & (NSLOT - 1)) * STAGE_BYTES) + lane;
@@ -303,11 +302,11 @@ struct Pipe {
   }
   // middle of stage g: stage g+1 must be in LDS for everyone; slot of g-1 is free afterwards
   __device__ __forceinline__ void mid_sync() {
-    if (g + 2 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but the 8 pieces of stage g+2
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    dma_on = g + 3 < total;
+    // no tail special case: past the end the refill just re-reads the (wrapping) stream into a slot
+    // nobody consumes; the kernel drains vmcnt(0) before it exits
     dma_setup(g + 3);
   }
   __device__ __forceinline__ void advance() {
@@ -357,9 +356,7 @@ __device__ __forceinline__ void pair_step(Pipe& pipe, Frags& fr, floatx16& acc, 
   mfma1<AGPR, false>(acc, fr.hi[c], xhi);
   SCHED_FENCE();
   if constexpr (P == 7) pipe.mid_sync();
-  if constexpr (P >= 8) {
-    if (pipe.dma_on) pipe.template dma_piece<P - 8>();
-  }
+  if constexpr (P >= 8) pipe.template dma_piece<P - 8>();
   extra();
   SCHED_FENCE();
   if constexpr (P == STAGE_PAIRS - 1) pipe.advance();
@@ -574,7 +571,6 @@ __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
   pipe.dma_setup(0); pipe.dma_all();
   pipe.dma_setup(1); pipe.dma_all();
   pipe.dma_setup(2); pipe.dma_all();
-  pipe.dma_on = false;
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -613,6 +609,7 @@ __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
     float pred = __fadd_rn(g, l);   // reference models/model_normalization.py:204
     if (valid && pipe.lane < 32) a.out[p] = a.scale_out ? (float)((double)pred / 10.0) : pred;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
 }  // namespace
