@@ -72,10 +72,18 @@ def main(argv=None):
     enc = Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed))
     img = read_image(FLAGS.image) if FLAGS.image else synth.image(FLAGS.seed)
     if FLAGS.cam_est:
-        raise SystemExit("demo: the camera estimator forward is the next scope row (SURVEY.md s8f2); "
-                         "run without --cam_est to use the demo's ground-truth camera")
-    log("here we use gt cam parameters")
-    trans_mat = synth.GT_TRANS_MAT                     # reference demo/demo.py:272-276
+        # reference demo/demo.py:195-258: a second VGG-16 (own weights) + the pose heads
+        from . import camera
+        log("here we use our cam est network to estimate cam parameters:")
+        if os.path.exists(os.path.join(FLAGS.cam_log_dir, "checkpoint")):
+            raise SystemExit("demo: TF checkpoint reading is the next scope row (SURVEY.md s8f1)")
+        log("demo: no checkpoint at %s -> seeded random-init camera network" % FLAGS.cam_log_dir)
+        cam_emb, _ = Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed + 1))(img)
+        trans_mat = camera.pred_trans_mat(cam_emb, camera.random_weights(FLAGS.seed))[0].cpu().numpy()
+        log("pred_trans_mat_val", trans_mat)
+    else:
+        log("here we use gt cam parameters")
+        trans_mat = synth.GT_TRANS_MAT                 # reference demo/demo.py:272-276
     sdf_params = (-1, -1, -1, 1, 1, 1)                 # reference demo/demo.py:278
     t0 = time.time()
     gfeat, feats = enc(img)

@@ -252,3 +252,32 @@ def synthetic_features(seed=0, scale=1.0):
         maps.append(np.maximum(m, 0) * np.float32(scale))
     g = rng.standard_normal(1024).astype(np.float32)
     return maps, g
+
+
+# ---- camera estimator (once per image; reference demo/demo.py:195-258) ---------
+def cam_pred_trans_mat(embedding, w):
+    """numpy restatement of cam_est/model_cam_old.py:82-106 + models/posenet_old.py:104-142.
+    embedding [1024], w: dict '<head>/fc<i>/{weights,biases}'.  Returns pred_trans_mat (4,3)."""
+    e = np.asarray(embedding, np.float32).reshape(1, 1024)
+
+    def head(name):
+        h = e
+        for li in (1, 2, 3):
+            h = h @ w["%s/fc%d/weights" % (name, li)] + w["%s/fc%d/biases" % (name, li)]
+            if li < 3:
+                h = np.maximum(h, 0)
+        return h[0]
+
+    def norm(v):
+        return v / max(np.sqrt((v * v).sum()), 1e-8)
+
+    scale = head("scale")[0]
+    p = head("ortho6d")
+    x = norm(p[0:3])
+    z = norm(np.cross(x, p[3:6]))
+    y = np.cross(z, x)
+    R = np.stack([x, y, z], axis=1)                               # columns x, y, z
+    t = head("translation") + np.array([-0.00193892, 0.00169222, 1.3949631], np.float32)
+    RT = np.concatenate([(scale * np.eye(3, dtype=np.float32)) @ R, t[None, :]], axis=0)
+    K = np.array([[149.84375, 0., 68.5], [0., 149.84375, 68.5], [0., 0., 1.]], dtype=np.float32)
+    return (RT @ K.T).astype(np.float32)
