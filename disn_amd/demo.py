@@ -3,9 +3,10 @@ on the HIP path:  python -m disn_amd.demo --sdf_res 256 --img_feat_twostream
 
 Kept flags: --sdf_res --img_feat_twostream --cam_est --log_dir --cam_log_dir --iso
 --img_h --img_w --gpu (+ --image, --out, --ngpu is `torchrun --nproc-per-node`).
-Without a checkpoint reader the decoder / encoder run
-on seeded random-init weights and the tool says so; iso then defaults to the
-grid median so that a surface exists.
+Checkpoints are read without TensorFlow (disn_amd/tf_bundle.py).  When --log_dir
+holds none (the released ones are a separate download, README.md:39-50) the
+decoder / encoder run on seeded random-init weights and the tool says so; iso
+then defaults to the grid median so that a surface exists.
 """
 import argparse
 import os
@@ -63,23 +64,31 @@ def main(argv=None):
     log = (lambda *a: print(*a, flush=True)) if rank == 0 else (lambda *a: None)
 
     ctx = api.Context(dev)
-    ckpt = os.path.join(FLAGS.log_dir, "checkpoint")
-    if os.path.exists(ckpt):
-        raise SystemExit("demo: TF checkpoint reading is the next scope row (SURVEY.md s8f1); remove --log_dir "
-                         "to run on random-init weights")
-    log("demo: no checkpoint at %s -> seeded random-init decoder/encoder weights (seed %d)" % (FLAGS.log_dir, FLAGS.seed))
-    ctx.set_weights(synth.decoder_weights(FLAGS.seed))
-    enc = Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed))
+    from . import tf_bundle
+    ckpt = tf_bundle.latest_checkpoint(FLAGS.log_dir)      # reference demo/demo.py:153-165 (but failing loudly)
+    if ckpt is not None:
+        log("Model loading from %s" % ckpt)
+        ctx.set_weights(tf_bundle.decoder_weights(ckpt))
+        enc = Vgg16Encoder(ctx, tf_bundle.vgg_weights(ckpt))
+    else:
+        log("demo: no checkpoint at %s -> seeded random-init decoder/encoder weights (seed %d)"
+            % (FLAGS.log_dir, FLAGS.seed))
+        ctx.set_weights(synth.decoder_weights(FLAGS.seed))
+        enc = Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed))
     img = read_image(FLAGS.image) if FLAGS.image else synth.image(FLAGS.seed)
     if FLAGS.cam_est:
         # reference demo/demo.py:195-258: a second VGG-16 (own weights) + the pose heads
         from . import camera
         log("here we use our cam est network to estimate cam parameters:")
-        if os.path.exists(os.path.join(FLAGS.cam_log_dir, "checkpoint")):
-            raise SystemExit("demo: TF checkpoint reading is the next scope row (SURVEY.md s8f1)")
-        log("demo: no checkpoint at %s -> seeded random-init camera network" % FLAGS.cam_log_dir)
-        cam_emb, _ = Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed + 1))(img)
-        trans_mat = camera.pred_trans_mat(cam_emb, camera.random_weights(FLAGS.seed))[0].cpu().numpy()
+        cam_ckpt = tf_bundle.latest_checkpoint(FLAGS.cam_log_dir)
+        if cam_ckpt is not None:
+            log("Model loading from %s" % cam_ckpt)
+            cam_vgg, cam_w = tf_bundle.vgg_weights(cam_ckpt), tf_bundle.camera_weights(cam_ckpt)
+        else:
+            log("demo: no checkpoint at %s -> seeded random-init camera network" % FLAGS.cam_log_dir)
+            cam_vgg, cam_w = synth.vgg_weights(FLAGS.seed + 1), camera.random_weights(FLAGS.seed)
+        cam_emb, _ = Vgg16Encoder(ctx, cam_vgg)(img)
+        trans_mat = camera.pred_trans_mat(cam_emb, cam_w)[0].cpu().numpy()
         log("pred_trans_mat_val", trans_mat)
     else:
         log("here we use gt cam parameters")
