@@ -222,6 +222,23 @@ def read_dist(path):
     return res.value, bb, v.reshape(n, n, n)
 
 
+def read_narrowband_dist(path):
+    """Narrow-band .n.dist (the reference tool's `-n` input) -> (res, bbox, dense grid [z,y,x], n_cells);
+    cells outside the band are +FLT_MAX."""
+    lib = _lib.load()
+    res, n = ctypes.c_int(), ctypes.c_int64()
+    bb = np.empty(6, np.float64)
+    rc = lib.disn_read_ndist_header(path.encode(), ctypes.byref(res), bb.ctypes.data, ctypes.byref(n))
+    if rc != 0:
+        raise DisnError("disn_read_ndist_header(%s) failed (%d)" % (path, rc))
+    n1 = res.value + 1
+    v = np.empty(n1 * n1 * n1, np.float32)
+    rc = lib.disn_read_ndist(path.encode(), v.ctypes.data, v.size)
+    if rc != 0:
+        raise DisnError("disn_read_ndist(%s) failed (%d)" % (path, rc))
+    return res.value, bb, v.reshape(n1, n1, n1), n.value
+
+
 def write_obj(path, verts, tris):
     v = np.ascontiguousarray(np.asarray(verts, dtype=np.float64).reshape(-1, 3))
     t = np.ascontiguousarray(np.asarray(tris, dtype=np.int32).reshape(-1, 3))

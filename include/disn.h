@@ -163,6 +163,12 @@ int disn_sort_triangles(DisnCtx* ctx, int32_t* tris, uint64_t n, uint64_t max_in
 int disn_write_dist(const char* path, int res, const double* bbox, const float* values);
 int disn_read_dist_header(const char* path, int* res, double* bbox);
 int disn_read_dist(const char* path, float* values, size_t n_values);
+/* Narrow-band .n.dist reader (the `-n` input mode of the reference tool; format of the shipped
+ * fixture isosurface/model_normalized.obj.n.dist): dense header, int32 N,
+ * N x (int32 i, j, k, float32 d).  disn_read_ndist expands it to a dense (res+1)^3 grid, x fastest,
+ * cells outside the band = +FLT_MAX (exterior).  HOST pointers. */
+int disn_read_ndist_header(const char* path, int* res, double* bbox, int64_t* n_cells);
+int disn_read_ndist(const char* path, float* values, size_t n_values);
 /* OBJ writer in the reference tool's text format:
  * header comments, `v x y z` with 6 significant digits, `f a b c` 1-based. */
 int disn_write_obj(const char* path, const double* verts, uint64_t n_verts, const int32_t* tris,

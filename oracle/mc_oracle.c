@@ -11,13 +11,17 @@
  * shift & nudge, B.2 voxel code, B.3 face/interior ambiguity tests, B.4 edge
  * vertices, B.5 centre vertex, B.6 ordering); each function cites its item.
  *
- * Pinning status: PARTIAL.  The reference holds no golden mesh for this step
- * (demo/result.obj is stripped) and prebuilt reference binaries
- * are not executed by this build.  The pins are the known answers the survey
- * recorded from the reference tool (r=0.6 sphere on a
- * res-8 grid -> 126 v / 248 t; s6: analytic 3-primitive field at res
- * 64/128/256 -> 8978/17940, 35690/71380, 143683/287370), checked in
- * tests/test_mc_oracle.py, plus the structural properties of the tables.
+ * Pinning status: pinned by the reference's own fixture and known answers, not by
+ * a golden mesh (the reference holds none: demo/result.obj is stripped, SURVEY.md s4;
+ * prebuilt reference binaries are not executed by this build):
+ *  - the reference's shipped data file isosurface/model_normalized.obj.n.dist
+ *    (narrow-band grid, res 64) meshes to exactly the size the reference tool
+ *    reports for it, 3800 v / 7604 t (tests/golden/ref_narrowband_res64.npz);
+ *  - the known answers the survey recorded from the tool (SURVEY.md App. A.1:
+ *    r=0.6 sphere on a res-8 grid -> 126 v / 248 t; s6: analytic 3-primitive field
+ *    at res 64/128/256 -> 8978/17940, 35690/71380, 143683/287370).
+ * All are checked in tests/test_mc_oracle.py.  Vertex positions and the face
+ * ORDER follow SURVEY.md App. B.4-B.6 and are not covered by those counts.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
  * -ffp-contract=off matters: B.3/B.4 specify separately rounded f32 products.

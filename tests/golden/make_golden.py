@@ -30,3 +30,17 @@ import torch  # noqa: E402
 f64 = net.sdf_points(pts, pts, net.GT_TRANS_MAT, maps, gf, w, dtype=torch.float64)
 np.savez_compressed(os.path.join(HERE, "net_points64.npz"), pts=pts, pred_f32=f32, pred_f64=f64)
 print("net_points64: max |f32-f64|", np.abs(f32 - f64).max())
+
+# ref_narrowband_res64.npz: the reference's own shipped data file isosurface/model_normalized.obj.n.dist
+# (narrow-band .dist, res 64, 69 149 cells) re-packed as arrays, with the mesh size the reference tool
+# reports for it with `-n 1` ("#v 3800 #t 7604").  Data fixture, not source.
+REF = "/root/reference/isosurface/model_normalized.obj.n.dist"
+if os.path.exists(REF):
+    import struct
+    b = open(REF, "rb").read()
+    n = struct.unpack_from("<i", b, 60)[0]
+    rec = np.frombuffer(b, dtype=np.dtype([("i", "<i4"), ("j", "<i4"), ("k", "<i4"), ("d", "<f4")]), count=n, offset=64)
+    np.savez_compressed(os.path.join(HERE, "ref_narrowband_res64.npz"),
+                        header=np.array(struct.unpack_from("<3i", b, 0), np.int32), bbox=np.array(struct.unpack_from("<6d", b, 12)),
+                        ijk=np.stack([rec["i"], rec["j"], rec["k"]], 1).astype(np.int16), d=rec["d"].copy(),
+                        expect_vt=np.array([3800, 7604]))

@@ -128,3 +128,14 @@ def test_slabs_reproduce_whole_grid(ctx, nslab):
     assert np.array_equal(tris, ref["tris"])
     assert np.array_equal(keys, ref["keys"])
     assert np.array_equal(verts, ref["verts"])
+
+
+def test_reference_narrowband_fixture(ctx, tmp_path):
+    """GPU on the reference's own shipped grid (narrow-band file): equals the oracle, and both give the
+    reference tool's reported size 3800 v / 7604 t."""
+    from disn_amd import api
+    from test_mc_oracle import _narrowband_file
+    p, z = _narrowband_file(tmp_path)
+    res, bbox, grid, _ = api.read_narrowband_dist(p)
+    ref = check(ctx, grid, 0.0, tuple(bbox))
+    assert (len(ref["verts"]), ref["n_tri"]) == (3800, 7604)

@@ -62,3 +62,30 @@ def test_golden_regression():
     r = mc.marching_cubes(z["grid"], iso=float(z["iso"]), bbox=tuple(z["bbox"]))
     assert np.array_equal(r["tris"], z["tris"])
     assert np.array_equal(r["verts"], z["verts"])
+
+
+def _narrowband_file(tmp_path):
+    """Re-create the reference's shipped narrow-band file from the golden arrays (tests/golden/make_golden.py)."""
+    import os
+    import struct
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_narrowband_res64.npz"))
+    p = str(tmp_path / "model_normalized.obj.n.dist")
+    with open(p, "wb") as f:
+        f.write(struct.pack("<3i", *z["header"]) + struct.pack("<6d", *z["bbox"]) + struct.pack("<i", len(z["d"])))
+        rec = np.zeros(len(z["d"]), dtype=np.dtype([("i", "<i4"), ("j", "<i4"), ("k", "<i4"), ("d", "<f4")]))
+        rec["i"], rec["j"], rec["k"], rec["d"] = z["ijk"][:, 0], z["ijk"][:, 1], z["ijk"][:, 2], z["d"]
+        f.write(rec.tobytes())
+    return p, z
+
+
+def test_reference_narrowband_fixture_known_answer(tmp_path):
+    """The reference's own data file meshes to exactly the size its tool reports with `-n 1`
+    (#v 3800 #t 7604): a reference fixture pinning the oracle."""
+    from disn_amd import api
+    p, z = _narrowband_file(tmp_path)
+    res, bbox, grid, n = api.read_narrowband_dist(p)
+    assert res == 64 and n == 69149 and np.array_equal(bbox, z["bbox"])
+    assert int((grid < 1e38).sum()) == 69149
+    r = mc.marching_cubes(grid, iso=0.0, bbox=tuple(bbox))
+    assert (len(r["verts"]), r["n_tri"]) == tuple(z["expect_vt"]) == (3800, 7604)
+    assert r["n_bad"] == 0 and fields.mesh_is_closed_manifold(r["tris"])
