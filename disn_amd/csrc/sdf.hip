@@ -239,13 +239,15 @@ struct DecodeArgs {
 
 // ---- weight pipeline: global -> LDS ring by LDS-DMA, shared by the 4 waves ----
 // The fragment stream is consumed in stages of 16 pairs (32 KiB).  Four ring
-// slots; while stage g is being multiplied, g+1 is already in LDS, g+2 is in
-// flight and g+3 is being issued.  The only rendezvous is in the MIDDLE of a
-// stage (after pair 7): every wave waits for its own part of stage g+1
-// (counted vmcnt), all meet at one s_barrier, and the slot of stage g-1, which
-// every wave has left by then, is refilled -- one 1 KiB LDS-DMA per wave after
-// each of pairs 8..15.  Fragment reads run three pairs ahead of their MFMAs
-// and cross stage boundaries, so a stage start costs nothing.
+// slots; while stage g is being multiplied, g+1 is in LDS (from the middle of g
+// on), g+2 is in flight and g+3 is being issued.  The only rendezvous is in the
+// MIDDLE of a stage (after pair 7): every wave waits for its own part of stage
+// g+1 (counted vmcnt), all meet at one s_barrier, and the slot of stage g-1,
+// which every wave has left by then, starts being refilled.  A refill period
+// runs from the middle of one stage to the middle of the next: two 256 B
+// LDS-DMA sub-pieces per wave in the MFMA shadows of every pair.  Fragment reads
+// run three pairs ahead of their MFMAs and cross stage boundaries, so a stage
+// start costs nothing.
 constexpr int STAGE_PAIRS = 16;                          // fragment pairs per stage
 constexpr int STAGE_BYTES = STAGE_PAIRS * 2048;          // 32 KiB
 constexpr int NSLOT = 4;                                 // ring slots
@@ -274,35 +276,47 @@ struct Pipe {
   int wave, lane;
   const uint4* cur;      // this lane's view of stage g / g+1 in LDS
   const uint4* nxt;
-  const char* dma_src;   // this lane's source of the stage being issued (g+3)
-  unsigned dma_dst;      // its LDS destination for this wave
+  const char* dma_src;   // uniform: this wave's 8 KiB share of the stage being issued (g+3), first / second half
+  const char* dma_src_hi;
+  unsigned dma_dst_hi;   // LDS address of the second half of its destination
+  unsigned voff;         // lane * 4
 
   __device__ __forceinline__ const uint4* slot_ptr(int stage) const {
     return (const uint4*)(ring + (stage & (NSLOT - 1)) * STAGE_BYTES) + lane;
   }
+  // M0 = LDS base of the LDS-DMA.  hipcc has no use for M0 in this kernel (gfx9+ DS
+  // instructions do not read it; `make check-m0` verifies it on the generated code), so it is
+  // written only here, twice per stage, far ahead of the instructions that read it.
   __device__ __forceinline__ void dma_setup(int stage) {
-    dma_src = ws + (size_t)(stage % STAGES_PER_TILE) * STAGE_BYTES + wave * (STAGE_BYTES / 4) + lane * 16;
-    dma_dst = ring32 + (stage & (NSLOT - 1)) * STAGE_BYTES + wave * (STAGE_BYTES / 4);
+    dma_src = ws + (size_t)(stage % STAGES_PER_TILE) * STAGE_BYTES + wave * (STAGE_BYTES / 4);
+    dma_src_hi = dma_src + 4096;
+    unsigned dst = ring32 + (stage & (NSLOT - 1)) * STAGE_BYTES + wave * (STAGE_BYTES / 4);
+    dma_dst_hi = dst + 4096;
+    asm volatile("s_mov_b32 m0, %0" ::"s"(dst) : "memory");
   }
-  // one 1 KiB piece (the instruction offset advances the global AND the LDS address):
-  // asm LDS-DMA so that hipcc does not count it (its own bookkeeping
-  // would drain vmcnt(0) before every ds_read); M0 is set and restored in the statement
-  template <int I>
-  __device__ __forceinline__ void dma_piece() const {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%4\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(dma_src + (I >= 4 ? 4096 : 0)), "s"(dma_dst), "i"(I >= 4 ? 4096 : 0), "i"((I & 3) * 1024)
+  __device__ __forceinline__ void dma_hi() const { asm volatile("s_mov_b32 m0, %0" ::"s"(dma_dst_hi) : "memory"); }
+  // one 256 B sub-piece J of the wave's share (the instruction offset advances the global AND the
+  // LDS address, so a half of 4 KiB shares one base).  Dword granularity and a scalar base on purpose:
+  // the issue cost of an LDS-DMA grows with its size (a 1 KiB dwordx4 piece outlasts the 32-cycle shadow
+  // of an MFMA and idles the matrix pipe), and every M0 write next to its use stalls the wave.  asm so
+  // that hipcc does not count it (its own bookkeeping would drain vmcnt(0) before every ds_read)
+  template <int J>
+  __device__ __forceinline__ void dma_sub() const {
+    asm volatile("global_load_lds_dword %0, %1 offset:%2"
+                 :
+                 : "v"(voff), "s"(J >= 16 ? dma_src_hi : dma_src), "i"((J & 15) * 256)
                  : "memory");
   }
-  __device__ __forceinline__ void dma_all() const {
-    dma_piece<0>(); dma_piece<1>(); dma_piece<2>(); dma_piece<3>();
-    dma_piece<4>(); dma_piece<5>(); dma_piece<6>(); dma_piece<7>();
+  template <int A, int B>
+  __device__ __forceinline__ void dma_range() const {   // sub-pieces A..B-1 (prologue only)
+    if constexpr (A < B) {
+      dma_sub<A>();
+      dma_range<A + 1, B>();
+    }
   }
   // middle of stage g: stage g+1 must be in LDS for everyone; slot of g-1 is free afterwards
   __device__ __forceinline__ void mid_sync() {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but the 8 pieces of stage g+2
+    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // all but the 32 sub-pieces of stage g+2
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // no tail special case: past the end the refill just re-reads the (wrapping) stream into a slot
@@ -339,25 +353,37 @@ __device__ __forceinline__ void drain_a(floatx16& acc) { asm("s_nop 15\n\ts_nop 
 
 // pair P of the current stage: w_lo*x_hi + w_hi*x_lo + w_hi*x_hi into acc, with the
 // fragment reads of pair P+3 (possibly in the next stage), the pipeline's
-// rendezvous / refill and the caller's filler work slotted between the MFMAs
+// rendezvous / refill and the caller's filler work slotted between the MFMAs.
+// extra(gap<M>) runs in the shadow of the M-th MFMA.  Measured budget (tools/mfma_cost.hip and the
+// per-stage cycle counts): a shadow has ~16 free issue cycles; the fragment read + refill piece fill
+// those of MFMAs 0 and 1, so filler VALU work belongs after MFMA 2, at most 4 ops per pair
+template <int M>
+using gap = std::integral_constant<int, M>;
 template <int P, bool AGPR, class Extra>
 __device__ __forceinline__ void pair_step(Pipe& pipe, Frags& fr, floatx16& acc, const bf16x8& xhi, const bf16x8& xlo,
                                           Extra extra) {
   constexpr int c = P & 3, n = (P + 3) & 3;
+  constexpr int J = 2 * ((P + 8) & 15);   // refill period runs from the middle of one stage to the middle of the next
   const uint4* src = (P + 3 < STAGE_PAIRS) ? pipe.cur + (P + 3) * 128 : pipe.nxt + (P + 3 - STAGE_PAIRS) * 128;
   mfma1<AGPR, true>(acc, fr.lo[c], xhi);
   SCHED_FENCE();
   fr.hi[n] = as_bf16x8(src[0]);
   SCHED_FENCE();
+  pipe.template dma_sub<J>();
+  extra(gap<0>{});
+  SCHED_FENCE();
   mfma1<AGPR, false>(acc, fr.hi[c], xlo);
   SCHED_FENCE();
   fr.lo[n] = as_bf16x8(src[64]);
   SCHED_FENCE();
+  pipe.template dma_sub<J + 1>();
+  if constexpr (J + 1 == 15) pipe.dma_hi();
+  extra(gap<1>{});
+  SCHED_FENCE();
   mfma1<AGPR, false>(acc, fr.hi[c], xhi);
   SCHED_FENCE();
   if constexpr (P == 7) pipe.mid_sync();
-  if constexpr (P >= 8) pipe.template dma_piece<P - 8>();
-  extra();
+  extra(gap<2>{});
   SCHED_FENCE();
   if constexpr (P == STAGE_PAIRS - 1) pipe.advance();
 }
@@ -385,6 +411,26 @@ __device__ __forceinline__ void cvt_pair(const floatx16& acc, int e, bf16x8 (&hi
   lo[e >> 3][(e & 7) + 1] = (__bf16)(v1 - (float)h1);
 }
 
+// the same conversion in three parts of <= 4 VALU ops, so that it can be spread over MFMA shadows:
+// T = 2 * (element pair) + part
+struct CvtState {
+  float v0, v1;
+};
+template <int T>
+__device__ __forceinline__ void cvt_part(const floatx16& acc, CvtState& st, bf16x8 (&hi)[2], bf16x8 (&lo)[2]) {
+  constexpr int e = 2 * (T / 2), part = T % 2;
+  if constexpr (part == 0) {
+    st.v0 = relu1(acc[e]);
+    st.v1 = relu1(acc[e + 1]);
+  } else {
+    __bf16 h0 = (__bf16)st.v0, h1 = (__bf16)st.v1;
+    hi[e >> 3][e & 7] = h0;
+    hi[e >> 3][(e & 7) + 1] = h1;
+    lo[e >> 3][e & 7] = (__bf16)(st.v0 - (float)h0);
+    lo[e >> 3][(e & 7) + 1] = (__bf16)(st.v1 - (float)h1);
+  }
+}
+
 // accumulator initialised with a per-feature vector: reg g <-> feature base + (g&3) + 8(g>>2) + 4h
 __device__ __forceinline__ floatx16 bias_init(const float* b, int base, int h) {
   floatx16 acc;
@@ -401,14 +447,16 @@ __device__ __forceinline__ void l3_stage(Pipe& pipe, Frags& fr, floatx16& acc3, 
                                          const bf16x8 (&h2lo)[16]) {
   static_for<16>([&](auto pc) {
     constexpr int P = decltype(pc)::value;
-    pair_step<P, false>(pipe, fr, acc3, h2hi[P], h2lo[P], [] {});
+    pair_step<P, false>(pipe, fr, acc3, h2hi[P], h2lo[P], [](auto) {});
   });
 }
 
 // one decoder stream for the wave's 32 points; sp = this stream's parameters in LDS
-template <bool LOCAL>
-__device__ float stream_pass(Pipe& pipe, Frags& fr, const float* sp, const float* __restrict__ pmap, float px, float py,
-                             float pz, float u, float v) {
+// LOCAL is a run-time (wave-uniform) flag on purpose: one copy of the ~50 KB stage code serves both
+// streams, so the loop over tiles stays inside the 64 KB instruction cache
+__device__ __forceinline__ float stream_pass(const bool LOCAL, Pipe& pipe, Frags& fr, const float* sp,
+                                             const float* __restrict__ pmap, float px, float py, float pz, float u,
+                                             float v) {
   const int lane = pipe.lane, h = lane >> 5;
   // fold2/conv1 accumulators (point part, 512 wide): bias (+ image term) first, while the
   // register file is still nearly empty so that many gather loads can be in flight
@@ -418,23 +466,39 @@ __device__ float stream_pass(Pipe& pipe, Frags& fr, const float* sp, const float
     asm volatile("" : "+v"(u), "+v"(v));   // keep hipcc from hoisting the gather above the previous stream
     cn = corners(u, v);
   }
-#pragma unroll
-  for (int nb4 = 0; nb4 < 16; ++nb4) {
-    acc4[nb4] = bias_init(sp + SP_B4, 32 * nb4, h);
-    if (LOCAL) {
-      // image part of fold2/conv1: bilinear blend of the pre-projected map
+  if (LOCAL) {
+    // image part of fold2/conv1: bilinear blend of the pre-projected map.  The 16 loads of block
+    // nb4+1 are issued before block nb4 is blended, so the memory latency is paid once, not 16 times
+    // (the phase is then bound by the texture-address path: 1 MiB per 128 points at 64 B/clk)
+    floatx4 t[2][16];
+    auto gather = [&](floatx4 (&dst)[16], int nb4) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float* src = pmap + (size_t)cn.pix[c] * 512 + 32 * nb4 + 4 * h;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          floatx4 t = *(const floatx4*)(src + 8 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc4[nb4][4 * q + e] = fmaf(cn.w[c], t[e], acc4[nb4][4 * q + e]);
-        }
+        for (int q = 0; q < 4; ++q) dst[4 * c + q] = *(const floatx4*)(src + 8 * q);
       }
+    };
+    gather(t[0], 0);
+    static_for<16>([&](auto nc) {
+      constexpr int nb4 = decltype(nc)::value;
+      if constexpr (nb4 + 1 < 16) gather(t[(nb4 + 1) & 1], nb4 + 1);
+      acc4[nb4] = bias_init(sp + SP_B4, 32 * nb4, h);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc4[nb4][4 * q + e] = fmaf(cn.w[c], t[nb4 & 1][4 * c + q][e], acc4[nb4][4 * q + e]);
+      asm volatile("" : "+a"(acc4[nb4]));   // park the block in the accumulator file now, not at its first MFMA
+    });
+  } else {
+#pragma unroll
+    for (int nb4 = 0; nb4 < 16; ++nb4) {
+      acc4[nb4] = bias_init(sp + SP_B4, 32 * nb4, h);
+      asm volatile("" : "+a"(acc4[nb4]));
     }
-    asm volatile("" : "+a"(acc4[nb4]));   // park the block in the accumulator file now, not at its first MFMA
   }
   // fold1/conv1 (3 -> 64) on the VALU, written straight into B-fragment order
   bf16x8 h1hi[4], h1lo[4];
@@ -461,7 +525,7 @@ __device__ float stream_pass(Pipe& pipe, Frags& fr, const float* sp, const float
     static_for<16>([&](auto pc) {
       constexpr int P = decltype(pc)::value;
       constexpr int b = P >> 2, ks = P & 3;
-      pair_step<P, false>(pipe, fr, acc2[b], h1hi[ks], h1lo[ks], [] {});
+      pair_step<P, false>(pipe, fr, acc2[b], h1hi[ks], h1lo[ks], [](auto) {});
     });
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -492,27 +556,31 @@ __device__ float stream_pass(Pipe& pipe, Frags& fr, const float* sp, const float
     floatx16 acc3n = bias_init(sp + SP_B3, 32 * (nb3 + 1), h);
     l3_stage(pipe, fr, acc3n, h2hi, h2lo);
     bf16x8 nhi[2], nlo[2];
+    CvtState cs;
+    // the split of block nb3+1 (16 parts) goes behind the third MFMA of pairs 1..8 of both stages;
+    // the first one comes 6 MFMAs after the last write of acc3n, so no drain is needed
     static_for<16>([&](auto pc) {
       constexpr int P = decltype(pc)::value;
-      pair_step<P, true>(pipe, fr, acc4[P >> 1], xhi[P & 1], xlo[P & 1], [&] {
-        if constexpr (P == 1) drain_v(acc3n);
-        if constexpr (P >= 2 && P < 10) cvt_pair(acc3n, 2 * (P - 2), nhi, nlo);
+      pair_step<P, true>(pipe, fr, acc4[P >> 1], xhi[P & 1], xlo[P & 1], [&](auto m) {
+        if constexpr (decltype(m)::value == 2 && P >= 1 && P <= 8) cvt_part<P - 1>(acc3n, cs, nhi, nlo);
       });
     });
     static_for<16>([&](auto pc) {
       constexpr int P = decltype(pc)::value;
-      pair_step<P, true>(pipe, fr, acc4[8 + (P >> 1)], xhi[P & 1], xlo[P & 1], [] {});
+      pair_step<P, true>(pipe, fr, acc4[8 + (P >> 1)], xhi[P & 1], xlo[P & 1], [&](auto m) {
+        if constexpr (decltype(m)::value == 2 && P >= 1 && P <= 8) cvt_part<8 + P - 1>(acc3n, cs, nhi, nlo);
+      });
     });
     xhi[0] = nhi[0]; xhi[1] = nhi[1]; xlo[0] = nlo[0]; xlo[1] = nlo[1];
   }
   // last block: nothing left to convert
   static_for<16>([&](auto pc) {
     constexpr int P = decltype(pc)::value;
-    pair_step<P, true>(pipe, fr, acc4[P >> 1], xhi[P & 1], xlo[P & 1], [] {});
+    pair_step<P, true>(pipe, fr, acc4[P >> 1], xhi[P & 1], xlo[P & 1], [](auto) {});
   });
   static_for<16>([&](auto pc) {
     constexpr int P = decltype(pc)::value;
-    pair_step<P, true>(pipe, fr, acc4[8 + (P >> 1)], xhi[P & 1], xlo[P & 1], [] {});
+    pair_step<P, true>(pipe, fr, acc4[8 + (P >> 1)], xhi[P & 1], xlo[P & 1], [](auto) {});
   });
   // fold2/conv2 (512 -> 256), consuming the fold2/conv1 accumulators block by block;
   // the split of block nb4+1 fills the gaps between the MFMAs of block nb4
@@ -520,6 +588,7 @@ __device__ float stream_pass(Pipe& pipe, Frags& fr, const float* sp, const float
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) acc5[nb] = bias_init(sp + SP_B5, 32 * nb, h);
   bf16x8 yhi[2][2], ylo[2][2];
+  CvtState cs5;
   drain_a(acc4[0]);
 #pragma unroll
   for (int e = 0; e < 16; e += 2) cvt_pair(acc4[0], e, yhi[0], ylo[0]);
@@ -528,11 +597,9 @@ __device__ float stream_pass(Pipe& pipe, Frags& fr, const float* sp, const float
     constexpr int cur = nb4 & 1, nx = cur ^ 1, nn = nb4 < 15 ? nb4 + 1 : 15;
     static_for<16>([&](auto pc) {
       constexpr int P = decltype(pc)::value;
-      pair_step<P, false>(pipe, fr, acc5[P >> 1], yhi[cur][P & 1], ylo[cur][P & 1], [&] {
-        if constexpr (nb4 < 15) {
-          if constexpr (P == 1) drain_a(acc4[nn]);
-          if constexpr (P >= 2 && P < 10) cvt_pair(acc4[nn], 2 * (P - 2), yhi[nx], ylo[nx]);
-        }
+      pair_step<P, false>(pipe, fr, acc5[P >> 1], yhi[cur][P & 1], ylo[cur][P & 1], [&](auto m) {
+        // block nn was last written a stage or more ago: no drain; one of its 16 parts per pair
+        if constexpr (nb4 < 15 && decltype(m)::value == 2) cvt_part<P>(acc4[nn], cs5, yhi[nx], ylo[nx]);
       });
     });
   });
@@ -568,10 +635,11 @@ __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
   pipe.total = (int)(mine * STAGES_PER_TILE);   // >= 132
   pipe.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   pipe.lane = threadIdx.x & 63;
-  pipe.dma_setup(0); pipe.dma_all();
-  pipe.dma_setup(1); pipe.dma_all();
-  pipe.dma_setup(2); pipe.dma_all();
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  pipe.voff = pipe.lane * 4;
+  pipe.dma_setup(0); pipe.dma_range<0, 16>(); pipe.dma_hi(); pipe.dma_range<16, 32>();
+  pipe.dma_setup(1); pipe.dma_range<0, 16>(); pipe.dma_hi(); pipe.dma_range<16, 32>();
+  pipe.dma_setup(2); pipe.dma_range<0, 16>(); pipe.dma_hi();   // second half: pairs 0..7 of stage 0
+  asm volatile("s_waitcnt vmcnt(48)" ::: "memory");   // stage 0 landed
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   pipe.cur = pipe.slot_ptr(0);
@@ -604,9 +672,10 @@ __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
     }
     float u, v;
     project(a.T, x, y, z, u, v);
-    float g = stream_pass<false>(pipe, fr, sp_lds, a.pmap, xr, yr, zr, u, v);
-    float l = stream_pass<true>(pipe, fr, sp_lds + SP_SIZE, a.pmap, xr, yr, zr, u, v);
-    float pred = __fadd_rn(g, l);   // reference models/model_normalization.py:204
+    float pred = 0.0f;   // global stream first, then local: pred = g + l (reference models/model_normalization.py:204)
+#pragma unroll 1
+    for (int strm = 0; strm < 2; ++strm)
+      pred = __fadd_rn(pred, stream_pass(strm != 0, pipe, fr, sp_lds + strm * SP_SIZE, a.pmap, xr, yr, zr, u, v));
     if (valid && pipe.lane < 32) a.out[p] = a.scale_out ? (float)((double)pred / 10.0) : pred;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation

@@ -1,0 +1,216 @@
+// mfma_cost.hip -- issue-cost table for the decoder's inner loop on gfx950 (experiment, not product).
+// One workgroup of 4 waves (1 per SIMD); every mode runs REP x 48 MFMAs (32x32x16 bf16) with a
+// different filler between them and reports shader cycles per MFMA (32 = matrix pipe saturated).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef __attribute__((ext_vector_type(16))) float floatx16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#define MV(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define MA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+
+template <int MODE, int UN = 1>
+__global__ __launch_bounds__(256, 1) void k(long long* out, const uint4* src, int rep, float seed) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const uint4* lp = (const uint4*)lds + threadIdx.x;
+  for (int i = threadIdx.x; i < 8192; i += 256) ((uint4*)lds)[i] = src[i];
+  __syncthreads();
+  bf16x8 a[4], b[2];
+  for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(bf16x8, lp[i * 256]);
+  for (int i = 0; i < 2; ++i) b[i] = __builtin_bit_cast(bf16x8, lp[(i + 4) * 256]);
+  floatx16 acc[4];
+  for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = seed * (i + e);
+  float f0 = seed, f1 = seed * 2, f2 = seed * 3, f3 = seed * 5;
+  unsigned voff = lane * 4;
+  unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
+  asm volatile("s_mov_b32 m0, %0" ::"s"(ldsbase + 65536));
+  long long t0 = clock64();
+#pragma unroll 1
+  for (int r = 0; r < rep; ++r) {
+#pragma unroll
+    for (int pp = 0; pp < 16 * UN; ++pp) {
+      const int p = pp & 15;
+      if constexpr (MODE == 0) {   // 4 independent VGPR accumulators round-robin
+        MV(acc[p & 3], a[0], b[0]); FENCE(); MV(acc[(p + 1) & 3], a[1], b[1]); FENCE(); MV(acc[(p + 2) & 3], a[2], b[0]); FENCE();
+      } else if constexpr (MODE == 1) {   // one VGPR accumulator, all dependent
+        MV(acc[0], a[0], b[0]); FENCE(); MV(acc[0], a[1], b[1]); FENCE(); MV(acc[0], a[2], b[0]); FENCE();
+      } else if constexpr (MODE == 2) {   // one AGPR accumulator, all dependent
+        MA(acc[0], a[0], b[0]); FENCE(); MA(acc[0], a[1], b[1]); FENCE(); MA(acc[0], a[2], b[0]); FENCE();
+      } else if constexpr (MODE == 3) {   // dependent triples, AGPR, block changes every pair
+        MA(acc[p & 3], a[0], b[0]); FENCE(); MA(acc[p & 3], a[1], b[1]); FENCE(); MA(acc[p & 3], a[2], b[0]); FENCE();
+      } else if constexpr (MODE == 4) {   // triples + s_nop 1 lead
+        asm volatile("s_nop 1"); MA(acc[p & 3], a[0], b[0]); FENCE(); MA(acc[p & 3], a[1], b[1]); FENCE(); MA(acc[p & 3], a[2], b[0]); FENCE();
+      } else if constexpr (MODE == 5) {   // triples + 2 ds_read_b128 into the operand ring
+        MA(acc[p & 3], a[p & 3], b[0]); FENCE();
+        a[(p + 3) & 3] = __builtin_bit_cast(bf16x8, lp[p * 256]); FENCE();
+        MA(acc[p & 3], a[(p + 1) & 3], b[1]); FENCE();
+        b[p & 1] = __builtin_bit_cast(bf16x8, lp[p * 256 + 4096]); FENCE();
+        MA(acc[p & 3], a[(p + 2) & 3], b[(p + 1) & 1]); FENCE();
+      } else if constexpr (MODE == 6) {   // triples + 2 LDS-DMA dword
+        MA(acc[p & 3], a[0], b[0]); FENCE();
+        asm volatile("global_load_lds_dword %0, %1 offset:0" ::"v"(voff), "s"(src) : "memory"); FENCE();
+        MA(acc[p & 3], a[1], b[1]); FENCE();
+        asm volatile("global_load_lds_dword %0, %1 offset:256" ::"v"(voff), "s"(src) : "memory"); FENCE();
+        MA(acc[p & 3], a[2], b[0]); FENCE();
+      } else if constexpr (MODE == 7) {   // triples + 1 LDS-DMA dwordx4 per pair
+        MA(acc[p & 3], a[0], b[0]); FENCE();
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:0" ::"v"(voff * 4), "s"(src) : "memory"); FENCE();
+        MA(acc[p & 3], a[1], b[1]); FENCE();
+        MA(acc[p & 3], a[2], b[0]); FENCE();
+      } else if constexpr (MODE >= 8 && MODE <= 11) {   // triples + N VALU ops after the third MFMA (N = 4, 8, 12, 16)
+        MA(acc[p & 3], a[0], b[0]); FENCE(); MA(acc[p & 3], a[1], b[1]); FENCE(); MA(acc[p & 3], a[2], b[0]); FENCE();
+#pragma unroll
+        for (int q = 0; q < (MODE - 7); ++q) {
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f0) : "v"(f1), "v"(f2));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f1) : "v"(f2), "v"(f3));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f2) : "v"(f3), "v"(f0));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f3) : "v"(f0), "v"(f1));
+        }
+        FENCE();
+      } else if constexpr (MODE >= 12 && MODE <= 15) {   // triples + N VALU ops spread over the three gaps (N = 6, 12, 18, 24)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          MA(acc[p & 3], a[m], b[m & 1]); FENCE();
+#pragma unroll
+          for (int q = 0; q < (MODE - 11); ++q) {
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f0) : "v"(f1), "v"(f2));
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f1) : "v"(f2), "v"(f3));
+          }
+          FENCE();
+        }
+      } else if constexpr (MODE >= 20 && MODE <= 29) {   // triples + ops of one kind after the third MFMA
+        MA(acc[p & 3], a[0], b[0]); FENCE(); MA(acc[p & 3], a[1], b[1]); FENCE(); MA(acc[p & 3], a[2], b[0]); FENCE();
+        unsigned u0, u1;
+        if constexpr (MODE == 20) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u0) : "v"(f0), "v"(f1)); asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u1) : "v"(f2), "v"(f3)); }
+        if constexpr (MODE == 21) { for (int q = 0; q < 2; ++q) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u0) : "v"(f0), "v"(f1)); asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u1) : "v"(f2), "v"(f3)); } }
+        if constexpr (MODE == 22) { for (int q = 0; q < 2; ++q) { asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(u0) : "v"(f0), "v"(f1), "v"(voff)); asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(u1) : "v"(f2), "v"(f3), "v"(voff)); } }
+        if constexpr (MODE == 23) { typedef __attribute__((ext_vector_type(2))) float f2t; f2t x = {f0, f1}, y = {f2, f3}; for (int q = 0; q < 4; ++q) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x) : "v"(y)); f0 = x[0]; }
+        if constexpr (MODE == 24) { for (int q = 0; q < 4; ++q) asm volatile("v_accvgpr_read_b32 %0, a0" : "=v"(u0)); }
+        if constexpr (MODE == 25) { for (int q = 0; q < 4; ++q) asm volatile("v_max_f32 %0, 0, %1" : "=v"(u0) : "v"(f0)); }
+        if constexpr (MODE == 26) { for (int q = 0; q < 8; ++q) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(u0) : "v"(f0), "v"(f1), "v"(voff)); }
+        if constexpr (MODE == 27) { for (int q = 0; q < 4; ++q) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(u0) : "v"(f0)); }
+        if constexpr (MODE == 28) { for (int q = 0; q < 4; ++q) asm volatile("v_accvgpr_write_b32 a255, %0" :: "v"(f0)); }
+        FENCE();
+      } else if constexpr (MODE == 16) {   // VGPR triples
+        MV(acc[p & 3], a[0], b[0]); FENCE(); MV(acc[p & 3], a[1], b[1]); FENCE(); MV(acc[p & 3], a[2], b[0]); FENCE();
+      } else if constexpr (MODE == 17) {   // everything of a plain pair: s_nop, 2 ds_read, 2 dma
+        asm volatile("s_nop 1");
+        MA(acc[p & 3], a[p & 3], b[0]); FENCE();
+        a[(p + 3) & 3] = __builtin_bit_cast(bf16x8, lp[p * 256]); FENCE();
+        asm volatile("global_load_lds_dword %0, %1 offset:0" ::"v"(voff), "s"(src) : "memory"); FENCE();
+        MA(acc[p & 3], a[(p + 1) & 3], b[1]); FENCE();
+        b[p & 1] = __builtin_bit_cast(bf16x8, lp[p * 256 + 4096]); FENCE();
+        asm volatile("global_load_lds_dword %0, %1 offset:256" ::"v"(voff), "s"(src) : "memory"); FENCE();
+        MA(acc[p & 3], a[(p + 2) & 3], b[(p + 1) & 1]); FENCE();
+      } else if constexpr (MODE >= 30 && MODE <= 35) {   // plain pair + VALU in all three shadows
+        constexpr int N01 = (MODE == 30) ? 1 : (MODE == 31) ? 2 : (MODE == 32) ? 3 : (MODE == 33) ? 4 : (MODE == 34) ? 2 : 0;
+        constexpr int N2 = (MODE == 34) ? 6 : (MODE == 35) ? 6 : 4;
+        asm volatile("s_nop 1");
+        MA(acc[p & 3], a[p & 3], b[0]); FENCE();
+        a[(p + 3) & 3] = __builtin_bit_cast(bf16x8, lp[p * 256]); FENCE();
+        asm volatile("global_load_lds_dword %0, %1 offset:0" ::"v"(voff), "s"(src) : "memory"); FENCE();
+#pragma unroll
+        for (int q = 0; q < N01; ++q) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f0) : "v"(f1), "v"(f2));
+        FENCE();
+        MA(acc[p & 3], a[(p + 1) & 3], b[1]); FENCE();
+        b[p & 1] = __builtin_bit_cast(bf16x8, lp[p * 256 + 4096]); FENCE();
+        asm volatile("global_load_lds_dword %0, %1 offset:256" ::"v"(voff), "s"(src) : "memory"); FENCE();
+#pragma unroll
+        for (int q = 0; q < N01; ++q) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f1) : "v"(f2), "v"(f3));
+        FENCE();
+        MA(acc[p & 3], a[(p + 2) & 3], b[(p + 1) & 1]); FENCE();
+#pragma unroll
+        for (int q = 0; q < N2; ++q) { if (q & 1) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f2) : "v"(f3), "v"(f0)); else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f3) : "v"(f0), "v"(f1)); }
+        FENCE();
+      } else if constexpr (MODE == 36 || MODE == 37) {   // plain pair with VGPR accumulators (one block / per-pair blocks)
+        const int blk = MODE == 36 ? 0 : (p & 3);
+        asm volatile("s_nop 1");
+        MV(acc[blk], a[p & 3], b[0]); FENCE();
+        a[(p + 3) & 3] = __builtin_bit_cast(bf16x8, lp[p * 256]); FENCE();
+        asm volatile("global_load_lds_dword %0, %1 offset:0" ::"v"(voff), "s"(src) : "memory"); FENCE();
+        MV(acc[blk], a[(p + 1) & 3], b[1]); FENCE();
+        b[p & 1] = __builtin_bit_cast(bf16x8, lp[p * 256 + 4096]); FENCE();
+        asm volatile("global_load_lds_dword %0, %1 offset:256" ::"v"(voff), "s"(src) : "memory"); FENCE();
+        MV(acc[blk], a[(p + 2) & 3], b[(p + 1) & 1]); FENCE();
+      } else if constexpr (MODE == 18) {   // as 17 with an s_barrier every 16 pairs
+        MA(acc[p & 3], a[p & 3], b[0]); FENCE();
+        a[(p + 3) & 3] = __builtin_bit_cast(bf16x8, lp[p * 256]); FENCE();
+        asm volatile("global_load_lds_dword %0, %1 offset:0" ::"v"(voff), "s"(src) : "memory"); FENCE();
+        MA(acc[p & 3], a[(p + 1) & 3], b[1]); FENCE();
+        b[p & 1] = __builtin_bit_cast(bf16x8, lp[p * 256 + 4096]); FENCE();
+        asm volatile("global_load_lds_dword %0, %1 offset:256" ::"v"(voff), "s"(src) : "memory"); FENCE();
+        MA(acc[p & 3], a[(p + 2) & 3], b[(p + 1) & 1]); FENCE();
+        if (p == 7) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+      }
+    }
+  }
+  long long t1 = clock64();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float s = f0 + f1 + f2 + f3;
+  for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+  for (int i = 0; i < 4; ++i) s += (float)a[i][0] + (float)b[i & 1][0];
+  if (s == 12345.678f) out[1] = 1;
+  if (threadIdx.x == 0) out[0] = t1 - t0;
+}
+
+template <int MODE, int UN = 1>
+void run(const char* name, long long* dout, const uint4* dsrc) {
+  const int rep = 2000 / UN;
+  hipFuncSetAttribute((const void*)k<MODE, UN>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+  long long h = 0;
+  hipMemset(dout, 0, 16);
+  for (int it = 0; it < 2; ++it) {
+    k<MODE, UN><<<dim3(1), dim3(256), 140 * 1024, 0>>>(dout, dsrc, rep, 1e-3f);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { printf("mode %d un %d: %s\n", MODE, UN, hipGetErrorString(e)); return; }
+    hipMemcpy(&h, dout, 8, hipMemcpyDeviceToHost);
+  }
+  printf("mode %2d  %-58s %6.2f cycles/MFMA  (%.0f per pair)\n", MODE, name, (double)h / (rep * 48.0 * UN), (double)h / (rep * 16.0 * UN));
+}
+
+int main() {
+  long long* dout; uint4* dsrc;
+  hipMalloc(&dout, 64); hipMalloc(&dsrc, 8192 * 16);
+  unsigned short* hb = (unsigned short*)malloc(8192 * 16);
+  for (int i = 0; i < 8192 * 8; ++i) hb[i] = 0x3c00 + (rand() & 0xff);   // bf16 values near 0.01..0.03
+  hipMemcpy(dsrc, hb, 8192 * 16, hipMemcpyHostToDevice);
+  run<0>("4 independent VGPR accumulators", dout, dsrc);
+  run<1>("one VGPR accumulator, dependent chain", dout, dsrc);
+  run<2>("one AGPR accumulator, dependent chain", dout, dsrc);
+  run<3>("AGPR dependent triples", dout, dsrc);
+  run<16>("VGPR dependent triples", dout, dsrc);
+  run<4>("AGPR triples + s_nop 1", dout, dsrc);
+  run<5>("AGPR triples + 2 ds_read_b128", dout, dsrc);
+  run<6>("AGPR triples + 2 LDS-DMA dword", dout, dsrc);
+  run<7>("AGPR triples + 1 LDS-DMA dwordx4", dout, dsrc);
+  run<8>("AGPR triples + 4 VALU after 3rd", dout, dsrc);
+  run<9>("AGPR triples + 8 VALU after 3rd", dout, dsrc);
+  run<10>("AGPR triples + 12 VALU after 3rd", dout, dsrc);
+  run<11>("AGPR triples + 16 VALU after 3rd", dout, dsrc);
+  run<12>("AGPR triples + 3x2 VALU spread", dout, dsrc);
+  run<13>("AGPR triples + 3x4 VALU spread", dout, dsrc);
+  run<14>("AGPR triples + 3x6 VALU spread", dout, dsrc);
+  run<15>("AGPR triples + 3x8 VALU spread", dout, dsrc);
+  run<17>("plain pair: s_nop, 2 ds_read, 2 dma", dout, dsrc);
+  run<18>("plain pair + waitcnt/barrier per 16 pairs", dout, dsrc);
+  run<20>("AGPR triples + 2 v_cvt_pk_bf16_f32", dout, dsrc);
+  run<21>("AGPR triples + 4 v_cvt_pk_bf16_f32", dout, dsrc);
+  run<22>("AGPR triples + 4 v_perm_b32", dout, dsrc);
+  run<26>("AGPR triples + 8 v_perm_b32", dout, dsrc);
+  run<23>("AGPR triples + 4 v_pk_add_f32", dout, dsrc);
+  run<24>("AGPR triples + 4 v_accvgpr_read", dout, dsrc);
+  run<28>("AGPR triples + 4 v_accvgpr_write", dout, dsrc);
+  run<25>("AGPR triples + 4 v_max_f32", dout, dsrc);
+  run<27>("AGPR triples + 4 v_and_b32", dout, dsrc);
+  run<30>("plain pair + VALU 1/1/4 in the three shadows", dout, dsrc);
+  run<31>("plain pair + VALU 2/2/4", dout, dsrc);
+  run<32>("plain pair + VALU 3/3/4", dout, dsrc);
+  run<33>("plain pair + VALU 4/4/4", dout, dsrc);
+  run<34>("plain pair + VALU 2/2/6", dout, dsrc);
+  run<35>("plain pair + VALU 0/0/6", dout, dsrc);
+  run<36>("plain pair, ONE VGPR accumulator (L3-like)", dout, dsrc);
+  run<37>("plain pair, VGPR accumulators per pair (L5-like)", dout, dsrc);
+  return 0;
+}
