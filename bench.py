@@ -141,6 +141,19 @@ def main():
                          "kernel_ms": dec_ms, "alg_flop_per_point": ALG_FLOP_PER_POINT,
                          "executed_mfma_tflops": mfma_tflops, "mfma_issue_frac": mfma_tflops / PEAK_BF16_TFLOPS},
         }
+        if world == 1 and pipe.mc_events:
+            # the HBM-bound parts: marching cubes against its algorithmic bytes
+            # 4 B/grid point + 24 B/vertex + 12 B/triangle, and the per-image precompute
+            mc_ms = float(np.mean([a.elapsed_time(b) for a, b in pipe.mc_events]))
+            img_ms = float(np.mean([a.elapsed_time(b) for a, b in pipe.image_events]))
+            mc_bytes = 4 * points + 24 * int(verts.shape[0]) + 12 * int(tris.shape[0])
+            out["other_kernels"] = {
+                "marching_cubes": {"bound": "hbm", "ms": mc_ms, "algorithmic_bytes": mc_bytes,
+                                   "achieved": mc_bytes / (mc_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                   "frac": mc_bytes / (mc_ms * 1e-3) / 1e9 / 8000.0,
+                                   "note": "count + emit + 9-pass triangle sort, incl. the host sync that returns the counts"},
+                "per_image_precompute": {"ms": img_ms, "note": "5 x resize to 137x137 + fp32 MFMA GEMM 18769x1472x512 + bias fold"},
+            }
         # HBM-side traffic of the dominant kernel, measured separately with rocprofv3 PMC passes
         # (tools/pmc_decode.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md) and committed under profiles/
         try:

@@ -415,19 +415,21 @@ __device__ __forceinline__ void cvt_pair(const floatx16& acc, int e, bf16x8 (&hi
 // T = 2 * (element pair) + part
 struct CvtState {
   float v0, v1;
+  __bf16 h0, h1;
 };
 template <int T>
 __device__ __forceinline__ void cvt_part(const floatx16& acc, CvtState& st, bf16x8 (&hi)[2], bf16x8 (&lo)[2]) {
   constexpr int e = 2 * (T / 2), part = T % 2;
-  if constexpr (part == 0) {
+  if constexpr (part == 0) {   // 3 VALU ops (5 when the accumulator has to be read out of an AGPR)
     st.v0 = relu1(acc[e]);
     st.v1 = relu1(acc[e + 1]);
-  } else {
-    __bf16 h0 = (__bf16)st.v0, h1 = (__bf16)st.v1;
-    hi[e >> 3][e & 7] = h0;
-    hi[e >> 3][(e & 7) + 1] = h1;
-    lo[e >> 3][e & 7] = (__bf16)(st.v0 - (float)h0);
-    lo[e >> 3][(e & 7) + 1] = (__bf16)(st.v1 - (float)h1);
+    st.h0 = (__bf16)st.v0;
+    st.h1 = (__bf16)st.v1;
+  } else {                     // 4 VALU ops, one of them two passes
+    hi[e >> 3][e & 7] = st.h0;
+    hi[e >> 3][(e & 7) + 1] = st.h1;
+    lo[e >> 3][e & 7] = (__bf16)(st.v0 - (float)st.h0);
+    lo[e >> 3][(e & 7) + 1] = (__bf16)(st.v1 - (float)st.h1);
   }
 }
 

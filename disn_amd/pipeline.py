@@ -53,8 +53,16 @@ class MeshPipeline:
         self.ctx, self.rank, self.world = ctx, rank, world
         self.dist = _Comm(dist) if world > 1 else None   # torch.distributed when world > 1
         self.decode_events = []     # (start, end) torch events around the decoder launch
+        self.image_events = []      # ... around the per-image precompute (resize, projected map)
+        self.mc_events = []         # ... around marching cubes (count + emit + sort), single GPU
         self.time_decode = False
         self.last_sdf = None
+
+    @staticmethod
+    def _mark():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
 
     def _broadcast_features(self, feats, gfeat):
         if self.world == 1:
@@ -69,7 +77,12 @@ class MeshPipeline:
         ctx = self.ctx
         nz = res + 1
         feats, gfeat = self._broadcast_features(feats, gfeat)
+        ev = (lambda: self._mark()) if self.time_decode else (lambda: None)
+        i0 = ev()
         ctx.set_image(feats, gfeat)
+        i1 = ev()
+        if i0 is not None:
+            self.image_events.append((i0, i1))
         lo, hi, own0, own1 = slab_ranges(nz, self.world)[self.rank] if self.world > 1 else (0, nz, 0, nz)
         if self.time_decode:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -81,9 +94,14 @@ class MeshPipeline:
         self.last_sdf = sdf
         if not want_mesh:
             return None, None
+        m0 = ev()
         counts = ctx.mc_count(sdf, iso, z_offset=lo, nz_global=nz, own=(own0, own1))
         if self.world == 1:
-            return ctx.mc_emit(sdf_params, sort=True)
+            mesh = ctx.mc_emit(sdf_params, sort=True)
+            m1 = ev()
+            if m0 is not None:
+                self.mc_events.append((m0, m1))
+            return mesh
         # ---- multi-GPU: exchange counts, emit with global indices, ship to rank 0
         mine = torch.tensor(counts, dtype=torch.int64, device=ctx.device)
         allc = [torch.empty_like(mine) for _ in range(self.world)]

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256, 1) void k(long long* out, const uint4* src, in
   unsigned voff = lane * 4;
   unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
   asm volatile("s_mov_b32 m0, %0" ::"s"(ldsbase + 65536));
+  long long w0 = wall_clock64();
   long long t0 = clock64();
 #pragma unroll 1
   for (int r = 0; r < rep; ++r) {
@@ -152,25 +153,29 @@ __global__ __launch_bounds__(256, 1) void k(long long* out, const uint4* src, in
   for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
   for (int i = 0; i < 4; ++i) s += (float)a[i][0] + (float)b[i & 1][0];
   if (s == 12345.678f) out[1] = 1;
-  if (threadIdx.x == 0) out[0] = t1 - t0;
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[2] = wall_clock64() - w0;
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
 }
 
+static int g_grid = 1;
 template <int MODE, int UN = 1>
 void run(const char* name, long long* dout, const uint4* dsrc) {
-  const int rep = 2000 / UN;
+  const int rep = (g_grid > 1 ? 20000 : 2000) / UN;
   hipFuncSetAttribute((const void*)k<MODE, UN>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
   long long h = 0;
   hipMemset(dout, 0, 16);
   for (int it = 0; it < 2; ++it) {
-    k<MODE, UN><<<dim3(1), dim3(256), 140 * 1024, 0>>>(dout, dsrc, rep, 1e-3f);
+    k<MODE, UN><<<dim3(g_grid), dim3(256), 140 * 1024, 0>>>(dout, dsrc, rep, 1e-3f);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) { printf("mode %d un %d: %s\n", MODE, UN, hipGetErrorString(e)); return; }
     hipMemcpy(&h, dout, 8, hipMemcpyDeviceToHost);
   }
-  printf("mode %2d  %-58s %6.2f cycles/MFMA  (%.0f per pair)\n", MODE, name, (double)h / (rep * 48.0 * UN), (double)h / (rep * 16.0 * UN));
+  long long hw = 0; hipMemcpy(&hw, dout + 2, 8, hipMemcpyDeviceToHost);
+  printf("mode %2d  %-58s %6.2f cycles/MFMA  (%.0f per pair)  %.2f GHz\n", MODE, name, (double)h / (rep * 48.0 * UN), (double)h / (rep * 16.0 * UN), (double)h / (hw * 10.0));
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) g_grid = atoi(argv[1]);
   long long* dout; uint4* dsrc;
   hipMalloc(&dout, 64); hipMalloc(&dsrc, 8192 * 16);
   unsigned short* hb = (unsigned short*)malloc(8192 * 16);
