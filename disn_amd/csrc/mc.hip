@@ -19,6 +19,7 @@
 #include <float.h>
 
 #include "common.h"
+#include <type_traits>
 
 #define DISN_MC_QUAL __device__
 #include "../../include/disn_mc_tables.h"
@@ -30,6 +31,25 @@ constexpr int ITEMS = 4;
 constexpr int TILE = BLK * ITEMS;
 constexpr unsigned NOSUB = 0x3ffu;
 
+// division of a 32-bit unsigned by a launch constant (Granlund-Montgomery round-up method):
+// the grid kernels are instruction-bound, and two hardware divisions per point were half of them
+struct FastDiv {
+  unsigned m, s1, s2;
+};
+static FastDiv make_fastdiv(unsigned n) {   // n >= 1
+  unsigned l = 0;
+  while ((1ull << l) < n) ++l;
+  FastDiv f;
+  f.m = (unsigned)((((1ull << 32) * ((1ull << l) - n)) / n) + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l < 1 ? 0 : l - 1;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned p, const FastDiv& f) {
+  unsigned t = __umulhi(f.m, p);
+  return (t + ((p - t) >> f.s1)) >> f.s2;
+}
+
 struct Dims {
   int nx, ny, nz;
   unsigned sxy;   // nx*ny
@@ -37,7 +57,15 @@ struct Dims {
   int own0, own1;
   int z_offset;
   float iso;
+  FastDiv dnx, dny;
 };
+__device__ __forceinline__ void point_ijk(const Dims& d, unsigned p, int& i, int& j, int& k) {
+  unsigned q = fdiv(p, d.dnx);
+  i = (int)(p - q * (unsigned)d.nx);
+  unsigned kk = fdiv(q, d.dny);
+  j = (int)(q - kk * (unsigned)d.ny);
+  k = (int)kk;
+}
 
 __device__ __forceinline__ float cval(const float* __restrict__ sdf, unsigned p, float iso) {
   float d = __fsub_rn(sdf[p], iso);  // B.1
@@ -146,77 +174,236 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* lds /*
 // counters per block: 0 E_all, 1 T_own, 2 C_own, 3 E_low, 4 E_own
 constexpr int NCNT = 5;
 
-__global__ __launch_bounds__(BLK) void mc_classify(const float* __restrict__ sdf, Dims d, uint16_t* __restrict__ info,
-                                                    unsigned* __restrict__ bsum, unsigned* __restrict__ layer_centre) {
-  __shared__ unsigned red[BLK / 64][NCNT];
-  unsigned cnt[NCNT] = {0, 0, 0, 0, 0};
-  const unsigned base = blockIdx.x * TILE;
-  for (int r = 0; r < ITEMS; ++r) {
-    unsigned p = base + r * BLK + threadIdx.x;
-    if (p >= d.P) break;
-    int i = p % d.nx;
-    unsigned q = p / d.nx;
-    int j = q % d.ny;
-    int k = q / d.ny;
-    const bool hx = i < d.nx - 1, hy = j < d.ny - 1, hz = k < d.nz - 1;
-    float c[8];
-    c[0] = cval(sdf, p, d.iso);
-    c[1] = hx ? cval(sdf, p + 1, d.iso) : 1.0f;
-    c[3] = hy ? cval(sdf, p + d.nx, d.iso) : 1.0f;
-    c[4] = hz ? cval(sdf, p + d.sxy, d.iso) : 1.0f;
-    unsigned flags = 0;
-    const bool has[3] = {hx, hy, hz};
-    const float cn[3] = {c[1], c[3], c[4]};
+// one grid point, cheap part: edge-slot flags (B.4, B.9) and the 8-bit corner code of its voxel
+// (0 when the voxel does not exist).  c[] holds the shifted corner values; corners outside the grid are 1.0f.
+__device__ __forceinline__ unsigned point_flags_code(const float* __restrict__ sdf, const Dims& d, int i, int j, int k,
+                                                     const float* c, bool hx, bool hy, bool hz, unsigned* code) {
+  unsigned flags = 0;
+  const bool has[3] = {hx, hy, hz};
+  const float cn[3] = {c[1], c[3], c[4]};
 #pragma unroll
-    for (int dir = 0; dir < 3; ++dir) {
-      if (!has[dir]) continue;
-      if (__fmul_rn(c[0], cn[dir]) <= 0.0f) {  // B.4
-        bool live = ((c[0] > 0.0f) != (cn[dir] > 0.0f)) || underflow_edge_live(sdf, d, i, j, k, dir);
-        if (live) flags |= 1u << dir;
+  for (int dir = 0; dir < 3; ++dir) {
+    if (!has[dir]) continue;
+    if (__fmul_rn(c[0], cn[dir]) <= 0.0f) {  // B.4
+      bool live = ((c[0] > 0.0f) != (cn[dir] > 0.0f)) || underflow_edge_live(sdf, d, i, j, k, dir);
+      if (live) flags |= 1u << dir;
+    }
+  }
+  unsigned cd = 0;
+  if (hx && hy && hz) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) cd |= (unsigned)(c[v] > 0.0f) << v;
+  }
+  *code = cd;
+  return flags;
+}
+
+// A tile = TILE consecutive points (the unit of the per-tile counters); a thread takes ITEMS = 4
+// consecutive points of it, so that the four voxels share their 20 corner values (instead of 32 loads)
+// and one index decomposition.  A workgroup takes CLS_TILES consecutive tiles and issues the loads of
+// all of them before using any: the kernel is bound by memory latency, not by bandwidth or ALU.
+// Voxels whose corners differ in sign are rare (the surface) but their sub-table lookup (face / interior
+// tests, B.3) is long: they are queued in LDS and classified by a dense set of lanes in a second phase,
+// instead of dragging whole waves through the long path once per point.
+constexpr int CLS_TILES = 1;
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte aligned address
+__global__ __launch_bounds__(BLK) void mc_classify(const float* __restrict__ sdf, Dims d, uint16_t* __restrict__ info,
+                                                    unsigned* __restrict__ bsum, unsigned nb,
+                                                    unsigned* __restrict__ layer_centre) {
+  __shared__ unsigned lcnt[CLS_TILES][NCNT];
+  __shared__ unsigned queue[CLS_TILES * TILE];
+  __shared__ unsigned short qsub[CLS_TILES * TILE];
+  __shared__ unsigned qn;
+  if (threadIdx.x == 0) qn = 0;
+  if (threadIdx.x < CLS_TILES * NCNT) (&lcnt[0][0])[threadIdx.x] = 0;
+  __syncthreads();
+  // per point: bits 0..2 edge flags, bit 3 plane below own0, bit 4 plane owned, bit 5 point exists
+  unsigned char meta[CLS_TILES][ITEMS];
+  short slot[CLS_TILES][ITEMS];
+  float raw[CLS_TILES][4][ITEMS + 1];
+  int ii[CLS_TILES], jj[CLS_TILES], kk[CLS_TILES];
+  bool interior[CLS_TILES];
+  // phase 0: issue the loads of every interior run
+#pragma unroll
+  for (int r = 0; r < CLS_TILES; ++r) {
+    const unsigned p0 = (blockIdx.x * CLS_TILES + r) * TILE + threadIdx.x * ITEMS;
+    interior[r] = false;
+    ii[r] = jj[r] = kk[r] = 0;
+    if (p0 < d.P) {
+      point_ijk(d, p0, ii[r], jj[r], kk[r]);
+      interior[r] = ii[r] + ITEMS < d.nx && jj[r] < d.ny - 1 && kk[r] < d.nz - 1;
+    }
+    if (interior[r]) {
+      // rows (j,k) (j+1,k) (j,k+1) (j+1,k+1), x = i .. i+4: one 16-byte load per row (rows are only
+      // 4-byte aligned: nx is odd) + the fifth value
+      const float* row[4] = {sdf + p0, sdf + p0 + d.nx, sdf + p0 + d.sxy, sdf + p0 + d.sxy + d.nx};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4u v = *(const float4u*)row[q];
+        raw[r][q][0] = v[0]; raw[r][q][1] = v[1]; raw[r][q][2] = v[2]; raw[r][q][3] = v[3];
+        raw[r][q][ITEMS] = row[q][ITEMS];
       }
     }
-    unsigned sub = NOSUB;
-    if (hx && hy && hz) {
-      c[2] = cval(sdf, p + 1 + d.nx, d.iso);
-      c[5] = cval(sdf, p + d.sxy + 1, d.iso);
-      c[6] = cval(sdf, p + d.sxy + 1 + d.nx, d.iso);
-      c[7] = cval(sdf, p + d.sxy + d.nx, d.iso);
-      sub = classify(c);
-    }
-    info[p] = (uint16_t)(sub | (flags << 10));
-    const unsigned ne = __popc(flags);
-    cnt[0] += ne;
-    if (k < d.own0) cnt[3] += ne;
-    if (k >= d.own0 && k < d.own1) {
-      cnt[4] += ne;
-      if (sub != NOSUB) {
-        const unsigned char* s = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub]];
-        cnt[1] += s[0] / 3;
-        if (s[1]) {
-          cnt[2] += 1;
-          atomicAdd(&layer_centre[k], 1u);
+  }
+  // phase 1: flags and corner codes; surface voxels go to the queue (unrolled by hand: the register
+  // arrays must keep compile-time indices)
+  auto phase1 = [&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    const unsigned p0 = (blockIdx.x * CLS_TILES + r) * TILE + threadIdx.x * ITEMS;
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) { meta[r][t] = 0; slot[r][t] = -1; }
+    if (p0 >= d.P) return;
+    int i = ii[r], j = jj[r], k = kk[r];
+    if (interior[r]) {
+      float c5[4][ITEMS + 1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t <= ITEMS; ++t) {
+          float v = __fsub_rn(raw[r][q][t], d.iso);   // B.1
+          c5[q][t] = v == 0.0f ? FLT_EPSILON : v;
+        }
+      const unsigned own = 32u | (k < d.own0 ? 8u : 0u) | ((k >= d.own0 && k < d.own1) ? 16u : 0u);
+#pragma unroll
+      for (int t = 0; t < ITEMS; ++t) {
+        const float c[8] = {c5[0][t], c5[0][t + 1], c5[1][t + 1], c5[1][t], c5[2][t], c5[2][t + 1], c5[3][t + 1], c5[3][t]};
+        unsigned code;
+        unsigned fl = point_flags_code(sdf, d, i + t, j, k, c, true, true, true, &code);
+        meta[r][t] = (unsigned char)(fl | own);
+        if (code != 0 && code != 255) {
+          slot[r][t] = (short)atomicAdd(&qn, 1u);
+          queue[slot[r][t]] = p0 + t;
+        }
+      }
+    } else {
+      // run touching a grid boundary (or the end of the grid): point by point
+#pragma unroll
+      for (int t = 0; t < ITEMS; ++t) {
+        const unsigned p = p0 + t;
+        if (p >= d.P) break;
+        const bool hx = i < d.nx - 1, hy = j < d.ny - 1, hz = k < d.nz - 1;
+        float c[8];
+        c[0] = cval(sdf, p, d.iso);
+        c[1] = hx ? cval(sdf, p + 1, d.iso) : 1.0f;
+        c[3] = hy ? cval(sdf, p + d.nx, d.iso) : 1.0f;
+        c[4] = hz ? cval(sdf, p + d.sxy, d.iso) : 1.0f;
+        if (hx && hy && hz) {
+          c[2] = cval(sdf, p + 1 + d.nx, d.iso);
+          c[5] = cval(sdf, p + d.sxy + 1, d.iso);
+          c[6] = cval(sdf, p + d.sxy + 1 + d.nx, d.iso);
+          c[7] = cval(sdf, p + d.sxy + d.nx, d.iso);
+        } else {
+          c[2] = c[5] = c[6] = c[7] = 1.0f;
+        }
+        unsigned code;
+        unsigned fl = point_flags_code(sdf, d, i, j, k, c, hx, hy, hz, &code);
+        meta[r][t] = (unsigned char)(fl | 32u | (k < d.own0 ? 8u : 0u) | ((k >= d.own0 && k < d.own1) ? 16u : 0u));
+        if (code != 0 && code != 255) {
+          slot[r][t] = (short)atomicAdd(&qn, 1u);
+          queue[slot[r][t]] = p;
+        }
+        if (++i == d.nx) {
+          i = 0;
+          if (++j == d.ny) { j = 0; ++k; }
         }
       }
     }
-  }
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int n = 0; n < NCNT; ++n) {
-    unsigned v = cnt[n];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if (lane == 0) red[w][n] = v;
+  };
+  phase1(std::integral_constant<int, 0>{});
+  if constexpr (CLS_TILES > 1) phase1(std::integral_constant<int, 1 % CLS_TILES>{});
+  if constexpr (CLS_TILES > 2) phase1(std::integral_constant<int, 2 % CLS_TILES>{});
+  if constexpr (CLS_TILES > 3) phase1(std::integral_constant<int, 3 % CLS_TILES>{});
+  static_assert(CLS_TILES <= 4, "phase1 is invoked once per tile");
+  __syncthreads();
+  // phase 2: the queued voxels (all of them have their 8 corners inside the grid)
+  for (unsigned e = threadIdx.x; e < qn; e += BLK) {
+    float c[8];
+    load_corners(sdf, d, queue[e], c);
+    qsub[e] = (unsigned short)classify(c);
   }
   __syncthreads();
-  if (threadIdx.x < NCNT) {
-    unsigned v = 0;
-    for (int q = 0; q < BLK / 64; ++q) v += red[q][threadIdx.x];
-    bsum[(size_t)blockIdx.x * NCNT + threadIdx.x] = v;
+  // phase 3: owners assemble info and the counters (0 E_all, 1 T_own, 2 C_own, 3 E_low, 4 E_own)
+#pragma unroll
+  for (int r = 0; r < CLS_TILES; ++r) {
+    const unsigned p0 = (blockIdx.x * CLS_TILES + r) * TILE + threadIdx.x * ITEMS;
+    if (p0 >= d.P) continue;
+    unsigned cnt[NCNT] = {0, 0, 0, 0, 0};
+    unsigned short out[ITEMS];
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+      const unsigned m = meta[r][t], fl = m & 7u;
+      const unsigned sub = slot[r][t] >= 0 ? (unsigned)qsub[slot[r][t]] : NOSUB;
+      out[t] = (unsigned short)(sub | (fl << 10));
+      const unsigned ne = __popc(fl);
+      cnt[0] += ne;
+      if (m & 8u) cnt[3] += ne;
+      if (m & 16u) {
+        cnt[4] += ne;
+        if (sub != NOSUB) {
+          const unsigned char* st = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub]];
+          cnt[1] += st[0] / 3;
+          if (st[1]) {
+            cnt[2] += 1;
+            int i, j, k;
+            point_ijk(d, p0 + t, i, j, k);
+            atomicAdd(&layer_centre[k], 1u);
+          }
+        }
+      }
+    }
+    if (interior[r]) {
+      uint2 pk;
+      pk.x = out[0] | ((unsigned)out[1] << 16);
+      pk.y = out[2] | ((unsigned)out[3] << 16);
+      *(uint2*)(info + p0) = pk;   // p0 is a multiple of 4
+    } else {
+#pragma unroll
+      for (int t = 0; t < ITEMS; ++t)
+        if (meta[r][t] & 32u) info[p0 + t] = out[t];
+    }
+#pragma unroll
+    for (int n = 0; n < NCNT; ++n)
+      if (cnt[n]) atomicAdd(&lcnt[r][n], cnt[n]);   // almost always nothing to add
+  }
+  __syncthreads();
+  if (threadIdx.x < CLS_TILES * NCNT) {
+    const unsigned tile = blockIdx.x * CLS_TILES + threadIdx.x / NCNT;
+    if (tile < nb) bsum[(size_t)tile * NCNT + threadIdx.x % NCNT] = (&lcnt[0][0])[threadIdx.x];
   }
 }
 
-// one workgroup of 1024 threads.  boff[b][0..2] = exclusive prefix of
-// (E_all, T_own, C_own); totals[0..4] = sums of the five counters (u64);
+// Two-level exclusive scan of the per-tile counters.  Level 1, one workgroup per chunk of SCAN_CHUNK
+// tiles: boff[b][0..2] = prefix of (E_all, T_own, C_own) inside the chunk, csum[chunk][0..4] = chunk sums.
+constexpr int SCAN_CHUNK = BLK * ITEMS;   // 1024 tiles
+__global__ __launch_bounds__(BLK) void mc_scan_tiles(const unsigned* __restrict__ bsum, unsigned nb,
+                                                     unsigned* __restrict__ boff, unsigned* __restrict__ csum) {
+  __shared__ unsigned lds[BLK / 64];
+  const unsigned b0 = blockIdx.x * SCAN_CHUNK + threadIdx.x * ITEMS;
+  unsigned v[ITEMS][NCNT];
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t)
+#pragma unroll
+    for (int n = 0; n < NCNT; ++n) v[t][n] = b0 + t < nb ? bsum[(size_t)(b0 + t) * NCNT + n] : 0u;
+#pragma unroll
+  for (int n = 0; n < NCNT; ++n) {
+    unsigned s = 0;
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) s += v[t][n];
+    unsigned tot;
+    unsigned run = block_excl_scan(s, lds, &tot);
+    if (threadIdx.x == 0) csum[(size_t)blockIdx.x * NCNT + n] = tot;
+    if (n < 3) {
+#pragma unroll
+      for (int t = 0; t < ITEMS; ++t) {
+        if (b0 + t < nb) boff[(size_t)(b0 + t) * 3 + n] = run;
+        run += v[t][n];
+      }
+    }
+  }
+}
+
+// Level 2, one workgroup of 1024 threads over the chunk sums (nb = number of chunks).  boff[c][0..2] =
+// exclusive prefix of (E_all, T_own, C_own) over the chunks; totals[0..4] = sums of the five counters (u64);
 // layer[k] (in: centres of layer k) -> layer_asc[k] = centres in layers < k.
 __global__ __launch_bounds__(1024) void mc_scan(const unsigned* __restrict__ bsum, unsigned nb, unsigned* __restrict__ boff,
                                                  unsigned long long* __restrict__ totals,
@@ -247,13 +434,25 @@ __global__ __launch_bounds__(1024) void mc_scan(const unsigned* __restrict__ bsu
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    unsigned run = 0;
-    for (int k = 0; k < nz; ++k) {
+  {
+    const int lchunk = (nz + 1023) / 1024;
+    const int k0 = min(nz, (int)threadIdx.x * lchunk), k1 = min(nz, k0 + lchunk);
+    unsigned long long s = 0;
+    for (int k = k0; k < k1; ++k) s += layer_centre[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      unsigned long long t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    unsigned run = (unsigned)(part[threadIdx.x] - s);
+    for (int k = k0; k < k1; ++k) {
       layer_asc[k] = run;
       run += layer_centre[k];
     }
-    layer_asc[nz] = run;
+    if (threadIdx.x == 1023) layer_asc[nz] = (unsigned)part[1023];
   }
 }
 
@@ -278,73 +477,100 @@ __device__ __forceinline__ void edge_position(const float* __restrict__ sdf, con
   pos[dir] = __dadd_rn(pos[dir], __ddiv_rn(__dmul_rn((double)ca, a.h[dir]), (double)diff));  // B.4
 }
 
-__global__ __launch_bounds__(BLK) void mc_vertices(const float* __restrict__ sdf, Dims d, const uint16_t* __restrict__ info,
-                                                    const unsigned* __restrict__ boff, unsigned* __restrict__ vbase,
-                                                    EmitArgs a) {
-  __shared__ unsigned lds[BLK / 64];
-  const unsigned base = blockIdx.x * TILE;
-  unsigned carry = boff[(size_t)blockIdx.x * 3 + 0];
-  for (int r = 0; r < ITEMS; ++r) {
-    unsigned p = base + r * BLK + threadIdx.x;
-    unsigned flags = p < d.P ? (unsigned)(info[p] >> 10) & 7u : 0u;
-    unsigned ne = __popc(flags), tot;
-    unsigned vb = carry + block_excl_scan(ne, lds, &tot);
-    carry += tot;
-    if (p >= d.P) continue;
-    vbase[p] = vb;
-    if (!flags) continue;
-    int i = p % d.nx;
-    unsigned q = p / d.nx;
-    int j = q % d.ny;
-    int k = q / d.ny;
-    if (k < d.own0 || k >= d.own1) continue;
-    unsigned long long out = (unsigned long long)a.c_own + (vb - a.e_low);
+// info of the ITEMS consecutive points of a thread (0 past the end of the grid)
+__device__ __forceinline__ void load_info4(const uint16_t* __restrict__ info, const Dims& d, unsigned p0, unsigned* w) {
+  if (p0 + ITEMS <= d.P) {
+    uint2 pk = *(const uint2*)(info + p0);   // p0 is a multiple of 4
+    w[0] = pk.x & 0xffffu; w[1] = pk.x >> 16; w[2] = pk.y & 0xffffu; w[3] = pk.y >> 16;
+  } else {
 #pragma unroll
-    for (int dir = 0; dir < 3; ++dir) {
-      if (!(flags >> dir & 1)) continue;
-      double pos[3];
-      edge_position(sdf, d, a, i, j, k, p, dir, pos);
-      a.verts[3 * out + 0] = pos[0];
-      a.verts[3 * out + 1] = pos[1];
-      a.verts[3 * out + 2] = pos[2];
-      if (a.keys)
-        a.keys[out] = 3ll * (((long long)(k + d.z_offset) * d.ny + j) * d.nx + i) + dir;
-      ++out;
+    for (int t = 0; t < ITEMS; ++t) w[t] = p0 + t < d.P ? info[p0 + t] : (unsigned)NOSUB;
+  }
+}
+
+// boff = prefix inside the chunk of SCAN_CHUNK tiles, coff = prefix over the chunks
+__global__ __launch_bounds__(BLK) void mc_vertices(const float* __restrict__ sdf, Dims d, const uint16_t* __restrict__ info,
+                                                    const unsigned* __restrict__ boff, const unsigned* __restrict__ coff,
+                                                    unsigned* __restrict__ vbase, EmitArgs a) {
+  __shared__ unsigned lds[BLK / 64];
+  const unsigned p0 = blockIdx.x * TILE + threadIdx.x * ITEMS;
+  unsigned w[ITEMS], fl[ITEMS], ne = 0;
+  load_info4(info, d, p0, w);
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t) {
+    fl[t] = (w[t] >> 10) & 7u;
+    ne += __popc(fl[t]);
+  }
+  unsigned tot;
+  unsigned vb = boff[(size_t)blockIdx.x * 3 + 0] + coff[(size_t)(blockIdx.x / SCAN_CHUNK) * 3 + 0] +
+                block_excl_scan(ne, lds, &tot);
+  if (!ne) return;
+  int i, j, k;
+  point_ijk(d, p0, i, j, k);
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t) {
+    const unsigned flags = fl[t], p = p0 + t;
+    if (flags) {
+      vbase[p] = vb;   // only slots that exist are ever looked up
+      if (k >= d.own0 && k < d.own1) {
+        unsigned long long out = (unsigned long long)a.c_own + (vb - a.e_low);
+#pragma unroll
+        for (int dir = 0; dir < 3; ++dir) {
+          if (!(flags >> dir & 1)) continue;
+          double pos[3];
+          edge_position(sdf, d, a, i, j, k, p, dir, pos);
+          a.verts[3 * out + 0] = pos[0];
+          a.verts[3 * out + 1] = pos[1];
+          a.verts[3 * out + 2] = pos[2];
+          if (a.keys)
+            a.keys[out] = 3ll * (((long long)(k + d.z_offset) * d.ny + j) * d.nx + i) + dir;
+          ++out;
+        }
+      }
+      vb += __popc(flags);
+    }
+    if (++i == d.nx) {
+      i = 0;
+      if (++j == d.ny) { j = 0; ++k; }
     }
   }
 }
 
 __global__ __launch_bounds__(BLK) void mc_triangles(const float* __restrict__ sdf, Dims d, const uint16_t* __restrict__ info,
-                                                     const unsigned* __restrict__ boff, const unsigned* __restrict__ vbase,
+                                                     const unsigned* __restrict__ boff, const unsigned* __restrict__ coff,
+                                                     const unsigned* __restrict__ vbase,
                                                      const unsigned* __restrict__ layer_asc, EmitArgs a) {
   __shared__ unsigned lds[BLK / 64];
-  const unsigned base = blockIdx.x * TILE;
-  unsigned carry_t = boff[(size_t)blockIdx.x * 3 + 1];
-  unsigned carry_c = boff[(size_t)blockIdx.x * 3 + 2];
-  for (int r = 0; r < ITEMS; ++r) {
-    unsigned p = base + r * BLK + threadIdx.x;
-    unsigned sub = NOSUB;
-    int i = 0, j = 0, k = 0;
-    if (p < d.P) {
-      i = p % d.nx;
-      unsigned q = p / d.nx;
-      j = q % d.ny;
-      k = q / d.ny;
-      if (k >= d.own0 && k < d.own1) sub = info[p] & NOSUB;
+  const unsigned p0 = blockIdx.x * TILE + threadIdx.x * ITEMS;
+  const unsigned own_lo = (unsigned)d.own0 * d.sxy, own_hi = (unsigned)d.own1 * d.sxy;   // owned layers as a point range
+  unsigned w[ITEMS], sub4[ITEMS], packed = 0;
+  load_info4(info, d, p0, w);
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t) {
+    const unsigned p = p0 + t;
+    sub4[t] = (p >= own_lo && p < own_hi) ? (w[t] & NOSUB) : (unsigned)NOSUB;
+    if (sub4[t] != NOSUB) {
+      const unsigned char* s = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub4[t]]];
+      packed += (unsigned)(s[0] / 3) | ((unsigned)s[1] << 16);
     }
-    const unsigned char* s = nullptr;
-    unsigned nt = 0, nc = 0;
-    if (sub != NOSUB) {
-      s = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub]];
-      nt = s[0] / 3;
-      nc = s[1];
+  }
+  unsigned tot;
+  const unsigned ex = block_excl_scan(packed, lds, &tot);
+  if (!packed) return;
+  const size_t ch = (size_t)(blockIdx.x / SCAN_CHUNK) * 3;
+  unsigned tb = boff[(size_t)blockIdx.x * 3 + 1] + coff[ch + 1] + (ex & 0xffffu);
+  unsigned cb = boff[(size_t)blockIdx.x * 3 + 2] + coff[ch + 2] + (ex >> 16);
+  int i, j, k;
+  point_ijk(d, p0, i, j, k);
+  for (int t = 0; t < ITEMS; ++t) {
+    const unsigned sub = sub4[t], p = p0 + t;
+    if (t > 0 && ++i == d.nx) {
+      i = 0;
+      if (++j == d.ny) { j = 0; ++k; }
     }
-    unsigned tot;
-    unsigned ex = block_excl_scan(nt | (nc << 16), lds, &tot);
-    unsigned tb = carry_t + (ex & 0xffffu), cb = carry_c + (ex >> 16);
-    carry_t += tot & 0xffffu;
-    carry_c += tot >> 16;
     if (sub == NOSUB) continue;
+    const unsigned char* s = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub]];
+    const unsigned nt = s[0] / 3, nc = s[1];
     // index of each of the 12 edges' vertices (only those referenced are read)
     long long centre_idx = -1;
     if (nc) {
@@ -371,11 +597,11 @@ __global__ __launch_bounds__(BLK) void mc_triangles(const float* __restrict__ sd
       a.verts[3 * (size_t)desc + 2] = __ddiv_rn(acc[2], (double)n);
       if (a.keys) a.keys[desc] = -(long long)(k + d.z_offset) * d.sxy + (long long)j * d.nx + i - 1;
     }
-    for (unsigned t = 0; t < nt; ++t) {
+    for (unsigned tt = 0; tt < nt; ++tt) {
       int v[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        int e = s[2 + 3 * t + q];
+        int e = s[2 + 3 * tt + q];
         if (e == 12) {
           v[q] = (int)centre_idx;
         } else {
@@ -389,11 +615,13 @@ __global__ __launch_bounds__(BLK) void mc_triangles(const float* __restrict__ sd
       if (v[1] < v[m]) m = 1;
       if (v[2] < v[m]) m = 2;
       int r0 = v[m], r1 = v[m == 2 ? 0 : m + 1], r2 = v[m == 0 ? 2 : m - 1];
-      int* o = a.tris + 3 * (size_t)(tb + t);
+      int* o = a.tris + 3 * (size_t)(tb + tt);
       o[0] = r0;
       o[1] = r1;
       o[2] = r2;
     }
+    tb += nt;
+    cb += nc;
   }
 }
 
@@ -489,7 +717,7 @@ __global__ __launch_bounds__(BLK) void tri_sort_scatter(const int* __restrict__ 
 }  // namespace
 
 struct McState {
-  DevBuf info, vbase, bsum, boff, layer, layer_asc, totals, sort_tmp, sort_hist;
+  DevBuf info, vbase, bsum, boff, csum, coff, layer, layer_asc, totals, sort_tmp, sort_hist;
   bool counted = false;
   const float* sdf = nullptr;
   Dims d{};
@@ -501,7 +729,7 @@ struct McState {
 void disn_mc_state_free(DisnCtx* ctx) {
   if (!ctx->mc) return;
   McState* m = ctx->mc;
-  DevBuf* all[] = {&m->info, &m->vbase, &m->bsum, &m->boff, &m->layer, &m->layer_asc, &m->totals, &m->sort_tmp, &m->sort_hist};
+  DevBuf* all[] = {&m->info, &m->vbase, &m->bsum, &m->boff, &m->csum, &m->coff, &m->layer, &m->layer_asc, &m->totals, &m->sort_tmp, &m->sort_hist};
   for (DevBuf* b : all) disn_release(*b);
   delete m;
   ctx->mc = nullptr;
@@ -535,17 +763,25 @@ extern "C" int disn_mc_count(DisnCtx* ctx, const float* sdf, const DisnMcGrid* g
   d.own0 = g->own0; d.own1 = g->own1;
   d.z_offset = g->z_offset;
   d.iso = iso;
+  d.dnx = make_fastdiv((unsigned)g->nx);
+  d.dny = make_fastdiv((unsigned)g->ny);
   const unsigned nb = (unsigned)((P64 + TILE - 1) / TILE);
   DISN_TRY(disn_ensure(ctx, m->info, P64 * sizeof(uint16_t)));
   DISN_TRY(disn_ensure(ctx, m->bsum, (size_t)nb * NCNT * sizeof(unsigned)));
   DISN_TRY(disn_ensure(ctx, m->boff, (size_t)nb * 3 * sizeof(unsigned)));
+  const unsigned nchunk = (nb + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  DISN_TRY(disn_ensure(ctx, m->csum, (size_t)nchunk * NCNT * sizeof(unsigned)));
+  DISN_TRY(disn_ensure(ctx, m->coff, (size_t)nchunk * 3 * sizeof(unsigned)));
   DISN_TRY(disn_ensure(ctx, m->layer, (size_t)(g->nz + 1) * sizeof(unsigned)));
   DISN_TRY(disn_ensure(ctx, m->layer_asc, (size_t)(g->nz + 2) * sizeof(unsigned)));
   DISN_TRY(disn_ensure(ctx, m->totals, NCNT * sizeof(unsigned long long)));
   DISN_HIP(ctx, hipMemsetAsync(m->layer.p, 0, (size_t)(g->nz + 1) * sizeof(unsigned), stream));
-  mc_classify<<<nb, BLK, 0, stream>>>(sdf, d, (uint16_t*)m->info.p, (unsigned*)m->bsum.p, (unsigned*)m->layer.p);
-  mc_scan<<<1, 1024, 0, stream>>>((const unsigned*)m->bsum.p, nb, (unsigned*)m->boff.p, (unsigned long long*)m->totals.p,
-                                  (const unsigned*)m->layer.p, (unsigned*)m->layer_asc.p, g->nz);
+  mc_classify<<<(nb + CLS_TILES - 1) / CLS_TILES, BLK, 0, stream>>>(sdf, d, (uint16_t*)m->info.p, (unsigned*)m->bsum.p, nb,
+                                                                    (unsigned*)m->layer.p);
+  mc_scan_tiles<<<nchunk, BLK, 0, stream>>>((const unsigned*)m->bsum.p, nb, (unsigned*)m->boff.p, (unsigned*)m->csum.p);
+  mc_scan<<<1, 1024, 0, stream>>>((const unsigned*)m->csum.p, nchunk, (unsigned*)m->coff.p,
+                                  (unsigned long long*)m->totals.p, (const unsigned*)m->layer.p,
+                                  (unsigned*)m->layer_asc.p, g->nz);
   DISN_HIP(ctx, hipGetLastError());
   DISN_HIP(ctx, hipMemcpyAsync(m->tot, m->totals.p, sizeof(m->tot), hipMemcpyDeviceToHost, stream));
   DISN_HIP(ctx, hipStreamSynchronize(stream));
@@ -611,9 +847,10 @@ extern "C" int disn_mc_emit(DisnCtx* ctx, const double* bbox, uint64_t centre_ba
   a.keys = (long long*)keys;
   a.tris = tris;
   mc_vertices<<<m->nb, BLK, 0, stream>>>(m->sdf, d, (const uint16_t*)m->info.p, (const unsigned*)m->boff.p,
-                                         (unsigned*)m->vbase.p, a);
+                                         (const unsigned*)m->coff.p, (unsigned*)m->vbase.p, a);
   mc_triangles<<<m->nb, BLK, 0, stream>>>(m->sdf, d, (const uint16_t*)m->info.p, (const unsigned*)m->boff.p,
-                                          (const unsigned*)m->vbase.p, (const unsigned*)m->layer_asc.p, a);
+                                          (const unsigned*)m->coff.p, (const unsigned*)m->vbase.p,
+                                          (const unsigned*)m->layer_asc.p, a);
   DISN_HIP(ctx, hipGetLastError());
   if (sort) DISN_TRY(sort_tris(ctx, m, tris, nt, max_index, stream));
   return DISN_OK;
