@@ -553,9 +553,12 @@ __device__ __forceinline__ float stream_pass(const bool LOCAL, Pipe& pipe, Frags
 #pragma unroll
     for (int e = 0; e < 16; e += 2) cvt_pair(acc3, e, xhi, xlo);
   }
+  // the bias of the block after next is fetched from LDS behind an MFMA of the previous stage, so a
+  // stage never starts with a wait on the LDS queue
+  floatx16 bnext = bias_init(sp + SP_B3, 32, h);
 #pragma unroll 1
   for (int nb3 = 0; nb3 < 15; ++nb3) {
-    floatx16 acc3n = bias_init(sp + SP_B3, 32 * (nb3 + 1), h);
+    floatx16 acc3n = bnext;
     l3_stage(pipe, fr, acc3n, h2hi, h2lo);
     bf16x8 nhi[2], nlo[2];
     CvtState cs;
@@ -571,6 +574,7 @@ __device__ __forceinline__ float stream_pass(const bool LOCAL, Pipe& pipe, Frags
       constexpr int P = decltype(pc)::value;
       pair_step<P, true>(pipe, fr, acc4[8 + (P >> 1)], xhi[P & 1], xlo[P & 1], [&](auto m) {
         if constexpr (decltype(m)::value == 2 && P >= 1 && P <= 8) cvt_part<8 + P - 1>(acc3n, cs, nhi, nlo);
+        if constexpr (decltype(m)::value == 2 && P == 11) bnext = bias_init(sp + SP_B3, 32 * (nb3 < 14 ? nb3 + 2 : 15), h);
       });
     });
     xhi[0] = nhi[0]; xhi[1] = nhi[1]; xlo[0] = nlo[0]; xlo[1] = nlo[1];
