@@ -10,7 +10,8 @@ is the once-per-image plumbing north_star excludes from the hot path.
 N=1: sdf_res=256 (BASELINE.json configs[1]).  N>1: ONE grid z-slab-sharded over
 the ranks with per-GPU points held at ~257^3 (res = round(256*N^(1/3)); N=8 is
 configs[2], sdf_res=512), RCCL broadcast of features + all-gather of counts,
-mesh assembled on rank 0 -> "weak" scaling.
+mesh assembled on rank 0 -> "weak" scaling.  Halo planes are exchanged (one all-gather of three boundary
+planes per rank), not recomputed, so every GPU evaluates exactly its own planes.
 """
 import argparse
 import json
@@ -121,7 +122,7 @@ def main():
 
     points = (res + 1) ** 3
     dec_ms = float(np.mean([a.elapsed_time(b) for a, b in pipe.decode_events]))
-    local_pts = pipe.last_sdf.numel()
+    local_pts = pipe.last_points
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         alg_tflops = local_pts * ALG_FLOP_PER_POINT / (dec_ms * 1e-3) / 1e12
@@ -135,7 +136,7 @@ def main():
             "config": {"workload": "sdf_res=%d two-stream, full sorted mesh output, %d z-slab(s)" % (res, world),
                        "sdf_res": res, "points": points, "mesh_vertices": int(verts.shape[0]),
                        "mesh_triangles": int(tris.shape[0]), "iso": iso,
-                       "per_gpu_points_incl_halo": local_pts},
+                       "per_gpu_points_evaluated": local_pts, "halo": pipe.halo if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": "sdf_decode", "achieved": alg_tflops, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": alg_tflops / PEAK_BF16_TFLOPS, "traffic": None,
                          "kernel_ms": dec_ms, "alg_flop_per_point": ALG_FLOP_PER_POINT,

@@ -36,11 +36,12 @@ if rank == 0:
 c = iso_t.cpu()
 dist.broadcast(c, src=0)
 iso = float(c.item())
-pipe = MeshPipeline(ctx, rank, world, dist)
+pipe = MeshPipeline(ctx, rank, world, dist, halo=os.environ.get("DISN_HALO", "exchange"))
 v, t = pipe.run(feats, gfeat, synth.GT_TRANS_MAT, res, iso, bbox)
 torch.cuda.synchronize()
 if rank == 0:
-    np.savez(sys.argv[1], tris_equal=torch.equal(t, t1), verts_equal=torch.equal(v, v1), n_tris=t.shape[0])
+    np.savez(sys.argv[1], tris_equal=torch.equal(t, t1), verts_equal=torch.equal(v, v1), n_tris=t.shape[0],
+             points=pipe.last_points, planes=pipe.last_sdf.shape[0])
 dist.barrier()
 dist.destroy_process_group()
 ctx.close()

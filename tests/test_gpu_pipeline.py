@@ -35,14 +35,18 @@ def test_single_rank_pipeline_matches_oracle(ctx):
     assert ref["n_tri"] > 100
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slab_sharded_pipeline_equals_single_rank(world, tmp_path):
+@pytest.mark.parametrize("world,halo", [(2, "exchange"), (3, "exchange"), (3, "recompute")])
+def test_slab_sharded_pipeline_equals_single_rank(world, halo, tmp_path):
     """torchrun, `world` ranks on GPU 0, gloo backend (the box has one GPU; RCCL needs one device per
-    rank).  Exercises MeshPipeline's broadcast / count all-gather / send-recv / device sort."""
+    rank).  Exercises MeshPipeline's broadcast / halo all-gather / count all-gather / send-recv / device sort."""
     out = str(tmp_path / "r")
-    env = dict(os.environ, DISN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, DISN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", DISN_HALO=halo)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(29700 + world), os.path.join(ROOT, "tests", "dist_pipeline_worker.py"), out]
     subprocess.run(cmd, check=True, env=env, timeout=300, cwd=ROOT)
     z = np.load(out + ".npz")
     assert bool(z["tris_equal"]) and bool(z["verts_equal"]) and int(z["n_tris"]) > 100
+    # rank 0 of a 31-plane grid: with the exchange it evaluates only its own planes, the halo comes from rank 1
+    own = (30 * 1) // world
+    assert int(z["planes"]) == own + 2
+    assert int(z["points"]) == (own if halo == "exchange" else own + 2) * 31 * 31
