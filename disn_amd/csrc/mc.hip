@@ -504,34 +504,41 @@ __global__ __launch_bounds__(BLK) void mc_vertices(const float* __restrict__ sdf
   unsigned tot;
   unsigned vb = boff[(size_t)blockIdx.x * 3 + 0] + coff[(size_t)(blockIdx.x / SCAN_CHUNK) * 3 + 0] +
                 block_excl_scan(ne, lds, &tot);
-  if (!ne) return;
-  int i, j, k;
-  point_ijk(d, p0, i, j, k);
+  // points that own slots are rare (the surface): queue them and let a dense set of lanes emit
+  __shared__ unsigned qp[TILE], qv[TILE];
+  __shared__ unsigned char qf[TILE];
+  __shared__ unsigned qn;
+  if (threadIdx.x == 0) qn = 0;
+  __syncthreads();
 #pragma unroll
   for (int t = 0; t < ITEMS; ++t) {
-    const unsigned flags = fl[t], p = p0 + t;
-    if (flags) {
-      vbase[p] = vb;   // only slots that exist are ever looked up
-      if (k >= d.own0 && k < d.own1) {
-        unsigned long long out = (unsigned long long)a.c_own + (vb - a.e_low);
-#pragma unroll
-        for (int dir = 0; dir < 3; ++dir) {
-          if (!(flags >> dir & 1)) continue;
-          double pos[3];
-          edge_position(sdf, d, a, i, j, k, p, dir, pos);
-          a.verts[3 * out + 0] = pos[0];
-          a.verts[3 * out + 1] = pos[1];
-          a.verts[3 * out + 2] = pos[2];
-          if (a.keys)
-            a.keys[out] = 3ll * (((long long)(k + d.z_offset) * d.ny + j) * d.nx + i) + dir;
-          ++out;
-        }
-      }
-      vb += __popc(flags);
+    if (fl[t]) {
+      const unsigned e = atomicAdd(&qn, 1u);
+      qp[e] = p0 + t;
+      qv[e] = vb;
+      qf[e] = (unsigned char)fl[t];
+      vb += __popc(fl[t]);
     }
-    if (++i == d.nx) {
-      i = 0;
-      if (++j == d.ny) { j = 0; ++k; }
+  }
+  __syncthreads();
+  for (unsigned e = threadIdx.x; e < qn; e += BLK) {
+    const unsigned p = qp[e], flags = qf[e], v0 = qv[e];
+    vbase[p] = v0;   // only slots that exist are ever looked up
+    int i, j, k;
+    point_ijk(d, p, i, j, k);
+    if (k < d.own0 || k >= d.own1) continue;
+    unsigned long long out = (unsigned long long)a.c_own + (v0 - a.e_low);
+#pragma unroll
+    for (int dir = 0; dir < 3; ++dir) {
+      if (!(flags >> dir & 1)) continue;
+      double pos[3];
+      edge_position(sdf, d, a, i, j, k, p, dir, pos);
+      a.verts[3 * out + 0] = pos[0];
+      a.verts[3 * out + 1] = pos[1];
+      a.verts[3 * out + 2] = pos[2];
+      if (a.keys)
+        a.keys[out] = 3ll * (((long long)(k + d.z_offset) * d.ny + j) * d.nx + i) + dir;
+      ++out;
     }
   }
 }
@@ -556,19 +563,31 @@ __global__ __launch_bounds__(BLK) void mc_triangles(const float* __restrict__ sd
   }
   unsigned tot;
   const unsigned ex = block_excl_scan(packed, lds, &tot);
-  if (!packed) return;
   const size_t ch = (size_t)(blockIdx.x / SCAN_CHUNK) * 3;
   unsigned tb = boff[(size_t)blockIdx.x * 3 + 1] + coff[ch + 1] + (ex & 0xffffu);
   unsigned cb = boff[(size_t)blockIdx.x * 3 + 2] + coff[ch + 2] + (ex >> 16);
-  int i, j, k;
-  point_ijk(d, p0, i, j, k);
+  // active voxels are rare (the surface): queue them and let a dense set of lanes emit
+  __shared__ unsigned qp[TILE], qt[TILE], qc[TILE];
+  __shared__ unsigned short qs[TILE];
+  __shared__ unsigned qn;
+  if (threadIdx.x == 0) qn = 0;
+  __syncthreads();
+#pragma unroll
   for (int t = 0; t < ITEMS; ++t) {
-    const unsigned sub = sub4[t], p = p0 + t;
-    if (t > 0 && ++i == d.nx) {
-      i = 0;
-      if (++j == d.ny) { j = 0; ++k; }
+    if (sub4[t] != NOSUB) {
+      const unsigned char* st = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub4[t]]];
+      const unsigned e = atomicAdd(&qn, 1u);
+      qp[e] = p0 + t; qt[e] = tb; qc[e] = cb; qs[e] = (unsigned short)sub4[t];
+      tb += st[0] / 3;
+      cb += st[1];
     }
-    if (sub == NOSUB) continue;
+  }
+  __syncthreads();
+  for (unsigned qe = threadIdx.x; qe < qn; qe += BLK) {
+    const unsigned p = qp[qe], sub = qs[qe];
+    unsigned tb = qt[qe], cb = qc[qe];
+    int i, j, k;
+    point_ijk(d, p, i, j, k);
     const unsigned char* s = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub]];
     const unsigned nt = s[0] / 3, nc = s[1];
     // index of each of the 12 edges' vertices (only those referenced are read)
@@ -620,8 +639,6 @@ __global__ __launch_bounds__(BLK) void mc_triangles(const float* __restrict__ sd
       o[1] = r1;
       o[2] = r2;
     }
-    tb += nt;
-    cb += nc;
   }
 }
 
