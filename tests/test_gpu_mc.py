@@ -173,3 +173,13 @@ def test_contexts_are_reentrant_across_threads():
     assert not errs, errs
     for (v, f), ref in zip(out, refs):
         assert np.array_equal(f, ref["tris"]) and np.array_equal(v, ref["verts"], equal_nan=True)
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 2), (2, 3, 5), (3, 2, 2), (5, 4, 3), (4, 4, 4), (9, 2, 7), (3, 3, 1031),
+                                   (2, 1029, 3), (6, 5, 4), (33, 2, 2), (2, 2, 260)])
+def test_tiny_and_skewed_grids(ctx, shape):
+    """rows shorter than a thread's run of 4 points, rows longer than a tile, tiles that end mid-row:
+    the boundary path of every kernel (shape is (nz, ny, nx))"""
+    g = fields.noise_field(shape, seed=sum(shape))
+    check(ctx, g, iso=0.0)
+    check(ctx, g, iso=0.2, bbox=(-1, -2, -3, 2, 1, 0.5))
