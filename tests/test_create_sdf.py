@@ -68,3 +68,19 @@ def test_h5_source_fails_loudly_without_h5py():
     except ImportError:
         with pytest.raises(SystemExit):
             list(create_sdf.h5_views("a", "b", [("c", "o", 0)], False))
+
+
+def test_demo_reads_the_reference_image_like_cv2():
+    """tests/golden/demo_chair_20.png is the reference's own demo input (demo/03001627_..._20.png, data, RGBA).
+    cv2.imread(IMREAD_UNCHANGED)[:, :, :3] / 255 (reference demo/demo.py:263-264) = the raw colour channels in
+    BGR order, alpha dropped, no compositing."""
+    from PIL import Image
+    from disn_amd import demo
+    path = os.path.join(os.path.dirname(__file__), "golden", "demo_chair_20.png")
+    img = demo.read_image(path)
+    raw = np.asarray(Image.open(path))
+    assert raw.shape == (137, 137, 4)
+    assert img.shape == (137, 137, 3) and img.dtype == np.float32
+    assert np.array_equal(img[:, :, 0], raw[:, :, 2].astype(np.float32) / np.float32(255.0))   # B
+    assert np.array_equal(img[:, :, 2], raw[:, :, 0].astype(np.float32) / np.float32(255.0))   # R
+    assert 0.0 <= float(img.min()) and float(img.max()) <= 1.0 and float(img.std()) > 0.01
