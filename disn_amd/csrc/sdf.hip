@@ -656,7 +656,18 @@ __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
     fr.hi[t] = as_bf16x8(pipe.cur[t * 128]);
     fr.lo[t] = as_bf16x8(pipe.cur[t * 128 + 64]);
   }
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Blocks b and b + 8 share an XCD (workgroups are dealt round-robin over the 8 XCDs): every XCD gets one
+  // contiguous eighth of the tiles, so that neighbouring tiles, which sample the same Pmap pixels, meet in the
+  // same L2 instead of pulling them into all eight.
+  long long tile_first = blockIdx.x, tile_end = ntiles, tile_step = gridDim.x;
+  if ((gridDim.x & 7) == 0) {
+    const long long per = (ntiles + 7) / 8;
+    const int xcd = blockIdx.x & 7;
+    tile_first = xcd * per + (blockIdx.x >> 3);
+    tile_end = min(ntiles, (xcd + 1) * per);
+    tile_step = gridDim.x >> 3;
+  }
+  for (long long tile = tile_first; tile < tile_end; tile += tile_step) {
     long long p = tile * 128 + pipe.wave * 32 + (pipe.lane & 31);
     const bool valid = p < a.n;
     if (!valid) p = a.n - 1;
