@@ -37,17 +37,45 @@ def cpu_baseline(res, trans_mat, feats_np, gfeat_np, weights, iso, budget_s=12.0
     from oracle import mc, net
     pts = net.grid_points(res)
     P = len(pts)
-    n0 = 32768
+    n0 = min(32768, P)
     t0 = time.time()
     net.sdf_points(pts[:n0], pts[:n0], trans_mat, feats_np, gfeat_np, weights)
     dt0 = time.time() - t0
-    n1 = int(min(P - n0, max(n0, (budget_s - dt0) / max(dt0, 1e-3) * n0)))
+    n1 = int(max(1, min(P, max(n0, (budget_s - dt0) / max(dt0, 1e-3) * n0))))
     sel = np.linspace(0, P - 1, n1).astype(np.int64)
     t0 = time.time()
     net.sdf_points(pts[sel], pts[sel], trans_mat, feats_np, gfeat_np, weights)
     dt1 = time.time() - t0
     net_pps = n1 / dt1
     return net_pps, n1, dt1, mc
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves as fresh children
+    (one process per GPU under torch.distributed.run), BEFORE this process touches the GPU -- a process that has
+    initialised HIP must never be replaced or forked into ranks.  The children print; rank 0's JSON line is
+    relayed on our stdout and any child failure is our exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if proc.returncode != 0 or len(lines) != 1:
+        print("bench.py: %d-rank launch failed (exit %d, %d result lines)" % (n, proc.returncode, len(lines)),
+              file=sys.stderr)
+        raise SystemExit(proc.returncode or 1)
+    print(lines[0], flush=True)
+    raise SystemExit(0)
 
 
 def main():
@@ -59,10 +87,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])          # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     if os.environ.get("DISN_DIST_BACKEND", "nccl") != "nccl":
@@ -79,7 +111,7 @@ def main():
     from disn_amd import synth
     from disn_amd.api import Context
     from disn_amd.encoder import Vgg16Encoder
-    from disn_amd.pipeline import MeshPipeline, median_iso
+    from disn_amd.pipeline import MeshPipeline, coarse_median_iso, median_iso
 
     res = args.res or (256 if world == 1 else int(round(256 * world ** (1.0 / 3.0))))
     ctx = Context(local_rank)
@@ -95,10 +127,14 @@ def main():
 
     # iso: median of the predicted grid so that random-init weights give a surface
     pipe.run(feats, gfeat, tm, res, want_mesh=False)
-    iso_t = torch.tensor([median_iso(pipe.last_sdf)], device=ctx.device)
-    if world > 1:
-        dist.broadcast(iso_t, src=0)
-    iso = float(iso_t.item())
+    if world == 1:
+        iso = median_iso(pipe.last_sdf)
+    else:
+        # a rank holds only its slab: the median of a coarse grid over the WHOLE box, which every rank
+        # computes from the (broadcast, bit-identical) features with the same kernel, then agreed on
+        iso_t = torch.tensor([coarse_median_iso(ctx, tm, res=64)], device=ctx.device)
+        pipe.dist.broadcast(iso_t, src=0)
+        iso = float(iso_t.item())
 
     def barrier():
         if world > 1:

@@ -147,7 +147,7 @@ class BatchMesher:
         return path
 
     def submit(self, view):
-        from .pipeline import median_iso
+        from .pipeline import coarse_median_iso
         t0 = time.perf_counter()
         gfeat, feats = self.enc(view["img"])
         trans_mat = view["trans_mat"]
@@ -158,8 +158,9 @@ class BatchMesher:
         params = tuple(float(v) for v in view["sdf_params"])
         iso = self.iso
         if self.median_iso:
-            self.pipe.run(feats, gfeat, trans_mat, self.res, sdf_params=params, want_mesh=False)
-            iso = median_iso(self.pipe.last_sdf)
+            # one coarse launch over the view's box (36 K points), not a second full grid
+            self.ctx.set_image(feats, gfeat)
+            iso = coarse_median_iso(self.ctx, trans_mat, params)
         verts, tris = self.pipe.run(feats, gfeat, trans_mat, self.res, iso, params)
         v, t = verts.cpu().numpy(), tris.cpu().numpy()        # synchronises
         sdf = self.pipe.last_sdf.cpu().numpy() if self.store_dist else None
@@ -193,7 +194,10 @@ def main(argv=None):
     ap.add_argument("--views_dir", default=None)
     ap.add_argument("--h5", nargs=2, metavar=("RENDERED_DIR", "SDF_DIR"), default=None)
     ap.add_argument("--store_dist", action="store_true")
-    ap.add_argument("--median_iso", action="store_true", help="iso = grid median per view (random-init weights)")
+    ap.add_argument("--median_iso", action="store_true",
+                    help="iso = median of a coarse grid over each view's box (implied by --random_init)")
+    ap.add_argument("--random_init", action="store_true",
+                    help="run on seeded random-init weights instead of checkpoints (no checkpoint is otherwise an error)")
     ap.add_argument("--seed", type=int, default=0)
     FLAGS = ap.parse_args(argv)
     if not FLAGS.img_feat_twostream:
@@ -208,25 +212,31 @@ def main(argv=None):
     torch.cuda.set_device(dev)
     log = (lambda *a: print(*a, flush=True)) if rank == 0 else (lambda *a: None)
     ctx = api.Context(dev)
-    ckpt = tf_bundle.latest_checkpoint(FLAGS.log_dir)
-    random_init = ckpt is None
+    random_init = FLAGS.random_init
     if not random_init:
+        ckpt = tf_bundle.latest_checkpoint(FLAGS.log_dir)
+        if ckpt is None:                      # the reference swallows this (test/create_sdf.py:188-196); we do not
+            raise SystemExit("create_sdf: no checkpoint under --log_dir %s (give --random_init to run on random "
+                             "weights)" % FLAGS.log_dir)
         log("Model loaded in file: %s" % ckpt)
         ctx.set_weights(tf_bundle.decoder_weights(ckpt))
         enc = Vgg16Encoder(ctx, tf_bundle.vgg_weights(ckpt))
     else:
-        log("create_sdf: no checkpoint at %s -> seeded random-init weights (seed %d)" % (FLAGS.log_dir, FLAGS.seed))
+        log("create_sdf: --random_init -> seeded random-init weights (seed %d)" % FLAGS.seed)
         ctx.set_weights(synth.decoder_weights(FLAGS.seed))
         enc = Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed))
     cam = None
     if FLAGS.cam_est:
         from . import camera
-        cam_ckpt = tf_bundle.latest_checkpoint(FLAGS.cam_log_dir)
-        if cam_ckpt is not None:
-            cam = (Vgg16Encoder(ctx, tf_bundle.vgg_weights(cam_ckpt)), tf_bundle.camera_weights(cam_ckpt))
-        else:
-            log("create_sdf: no checkpoint at %s -> seeded random-init camera network" % FLAGS.cam_log_dir)
+        if random_init:
+            log("create_sdf: --random_init -> seeded random-init camera network")
             cam = (Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed + 1)), camera.random_weights(FLAGS.seed))
+        else:
+            cam_ckpt = tf_bundle.latest_checkpoint(FLAGS.cam_log_dir)
+            if cam_ckpt is None:
+                raise SystemExit("create_sdf: no checkpoint under --cam_log_dir %s (give --random_init to run on "
+                                 "random weights)" % FLAGS.cam_log_dir)
+            cam = (Vgg16Encoder(ctx, tf_bundle.vgg_weights(cam_ckpt)), tf_bundle.camera_weights(cam_ckpt))
 
     if FLAGS.synthetic:
         views = synthetic_views(FLAGS.synthetic)

@@ -272,7 +272,6 @@ struct Pipe {
   char* ring;            // LDS ring base
   unsigned ring32;       // its LDS byte address
   int g;                 // stage being consumed (counts across tiles)
-  int total;             // stages this workgroup will consume in all
   int wave, lane;
   const uint4* cur;      // this lane's view of stage g / g+1 in LDS
   const uint4* nxt;
@@ -625,20 +624,19 @@ __device__ __forceinline__ float stream_pass(const bool LOCAL, Pipe& pipe, Frags
   return part + sp[SP_B6];
 }
 
-// persistent: one workgroup (4 waves x 32 points) per CU, tiles dealt round-robin
+// persistent: one workgroup (4 waves x 32 points) per CU; tiles are dealt per XCD (below), so a workgroup may
+// get no tile at all (e.g. 257 tiles on 256 CUs): it then only drains its prologue LDS-DMA and exits
 __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float* sp_lds = (float*)(lds + NSLOT * STAGE_BYTES);
   for (int i = threadIdx.x; i < SP_LDS_FLOATS; i += 256) sp_lds[i] = a.sp[i];
   __syncthreads();
   const long long ntiles = (a.n + 127) / 128;
-  const long long mine = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;   // >= 1: grid <= ntiles
   Pipe pipe;
   pipe.ws = (const char*)a.ws;
   pipe.ring = lds;
   pipe.ring32 = (unsigned)(size_t)(lds_ptr_t)lds;
   pipe.g = 0;
-  pipe.total = (int)(mine * STAGES_PER_TILE);   // >= 132
   pipe.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   pipe.lane = threadIdx.x & 63;
   pipe.voff = pipe.lane * 4;
@@ -703,7 +701,7 @@ __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
 struct SdfState {
   DevBuf ws, sp, f137, pmap, wimg, wglob, b4g, tmat;
   int num_cu = 256;
-  bool have_weights = false, have_image = false;
+  bool have_weights = false, have_image = false, lds_attr_set = false;
 };
 
 void disn_sdf_state_free(DisnCtx* ctx) {
@@ -877,7 +875,10 @@ static int launch_decode(DisnCtx* ctx, DecodeArgs& a, const float* trans_mat, hi
   const long long tiles = (a.n + 127) / 128;
   if (tiles * STAGES_PER_TILE > 0x7fffffffll) return disn_fail(ctx, DISN_E_ARG, "too many points for one launch");
   const unsigned blocks = (unsigned)(tiles < s->num_cu ? tiles : s->num_cu);
-  DISN_HIP(ctx, hipFuncSetAttribute((const void*)sdf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  if (!s->lds_attr_set) {   // once per context (the attribute is per device and function)
+    DISN_HIP(ctx, hipFuncSetAttribute((const void*)sdf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    s->lds_attr_set = true;
+  }
   sdf_decode<<<blocks, 256, LDS_BYTES, stream>>>(a);
   DISN_HIP(ctx, hipGetLastError());
   return DISN_OK;

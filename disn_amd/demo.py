@@ -3,10 +3,14 @@ on the HIP path:  python -m disn_amd.demo --sdf_res 256 --img_feat_twostream
 
 Kept flags: --sdf_res --img_feat_twostream --cam_est --log_dir --cam_log_dir --iso
 --img_h --img_w --gpu (+ --image, --out, --ngpu is `torchrun --nproc-per-node`).
-Checkpoints are read without TensorFlow (disn_amd/tf_bundle.py).  When --log_dir
-holds none (the released ones are a separate download, README.md:39-50) the
-decoder / encoder run on seeded random-init weights and the tool says so; iso
-then defaults to the grid median so that a surface exists.
+Checkpoints are read without TensorFlow (disn_amd/tf_bundle.py).  A --log_dir (or,
+with --cam_est, a --cam_log_dir) without a checkpoint is an ERROR (the reference
+swallows the failed restore and meshes random weights, demo/demo.py:157-165).
+--random_init is the explicit opt-in to seeded random-init decoder / encoder /
+camera weights (the released checkpoints are a separate download,
+README.md:39-50); iso then defaults to the median of a coarse whole-box grid so
+that a surface exists.  With a restored checkpoint --iso defaults to 0.0 like the
+reference (demo/demo.py:50).
 """
 import argparse
 import os
@@ -37,7 +41,10 @@ def main(argv=None):
     ap.add_argument("--cam_est", action="store_true")
     ap.add_argument("--log_dir", default="checkpoint/SDF_DISN")
     ap.add_argument("--cam_log_dir", default="cam_est/checkpoint/cam_DISN")
-    ap.add_argument("--iso", type=float, default=None)
+    ap.add_argument("--iso", type=float, default=None,
+                    help="iso value (default 0.0 as in the reference; with --random_init: median of a coarse grid)")
+    ap.add_argument("--random_init", action="store_true",
+                    help="run on seeded random-init weights instead of checkpoints (no checkpoint is otherwise an error)")
     ap.add_argument("--img_h", type=int, default=137)
     ap.add_argument("--img_w", type=int, default=137)
     ap.add_argument("--image", default=None, help="137x137 PNG (default: seeded synthetic view)")
@@ -51,7 +58,7 @@ def main(argv=None):
 
     from . import api, synth
     from .encoder import Vgg16Encoder
-    from .pipeline import MeshPipeline, median_iso
+    from .pipeline import MeshPipeline, coarse_median_iso
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -65,28 +72,33 @@ def main(argv=None):
 
     ctx = api.Context(dev)
     from . import tf_bundle
-    ckpt = tf_bundle.latest_checkpoint(FLAGS.log_dir)      # reference demo/demo.py:153-165 (but failing loudly)
-    if ckpt is not None:
+    if FLAGS.random_init:
+        log("demo: --random_init -> seeded random-init decoder/encoder weights (seed %d)" % FLAGS.seed)
+        ctx.set_weights(synth.decoder_weights(FLAGS.seed))
+        enc = Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed))
+    else:
+        ckpt = tf_bundle.latest_checkpoint(FLAGS.log_dir)      # reference demo/demo.py:153-165 (but failing loudly)
+        if ckpt is None:
+            raise SystemExit("demo: no checkpoint under --log_dir %s (give --random_init to run on random weights)"
+                             % FLAGS.log_dir)
         log("Model loading from %s" % ckpt)
         ctx.set_weights(tf_bundle.decoder_weights(ckpt))
         enc = Vgg16Encoder(ctx, tf_bundle.vgg_weights(ckpt))
-    else:
-        log("demo: no checkpoint at %s -> seeded random-init decoder/encoder weights (seed %d)"
-            % (FLAGS.log_dir, FLAGS.seed))
-        ctx.set_weights(synth.decoder_weights(FLAGS.seed))
-        enc = Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed))
     img = read_image(FLAGS.image) if FLAGS.image else synth.image(FLAGS.seed)
     if FLAGS.cam_est:
         # reference demo/demo.py:195-258: a second VGG-16 (own weights) + the pose heads
         from . import camera
         log("here we use our cam est network to estimate cam parameters:")
-        cam_ckpt = tf_bundle.latest_checkpoint(FLAGS.cam_log_dir)
-        if cam_ckpt is not None:
+        if FLAGS.random_init:
+            log("demo: --random_init -> seeded random-init camera network")
+            cam_vgg, cam_w = synth.vgg_weights(FLAGS.seed + 1), camera.random_weights(FLAGS.seed)
+        else:
+            cam_ckpt = tf_bundle.latest_checkpoint(FLAGS.cam_log_dir)
+            if cam_ckpt is None:
+                raise SystemExit("demo: no checkpoint under --cam_log_dir %s (give --random_init to run on random "
+                                 "weights)" % FLAGS.cam_log_dir)
             log("Model loading from %s" % cam_ckpt)
             cam_vgg, cam_w = tf_bundle.vgg_weights(cam_ckpt), tf_bundle.camera_weights(cam_ckpt)
-        else:
-            log("demo: no checkpoint at %s -> seeded random-init camera network" % FLAGS.cam_log_dir)
-            cam_vgg, cam_w = synth.vgg_weights(FLAGS.seed + 1), camera.random_weights(FLAGS.seed)
         cam_emb, _ = Vgg16Encoder(ctx, cam_vgg)(img)
         trans_mat = camera.pred_trans_mat(cam_emb, cam_w)[0].cpu().numpy()
         log("pred_trans_mat_val", trans_mat)
@@ -100,13 +112,15 @@ def main(argv=None):
         feats, gfeat = [torch.zeros_like(f) for f in feats], torch.zeros_like(gfeat)
     pipe = MeshPipeline(ctx, rank, world, dist)
     iso = FLAGS.iso
+    if iso is None and not FLAGS.random_init:
+        iso = 0.0                                      # reference demo/demo.py:50
     if iso is None:
-        pipe.run(feats, gfeat, trans_mat, FLAGS.sdf_res, want_mesh=False)
-        t = torch.tensor([median_iso(pipe.last_sdf)], device=ctx.device)
-        if world > 1:
-            dist.broadcast(t, src=0)
-        iso = float(t.item())
-        log("demo: --iso not given, using the grid median %.6g (random weights have no zero level set)" % iso)
+        # every rank holds the same features after this broadcast, so every rank computes the same number
+        feats, gfeat = pipe._broadcast_features(feats, gfeat)
+        ctx.set_image(feats, gfeat)
+        iso = coarse_median_iso(ctx, trans_mat, sdf_params)
+        log("demo: --random_init without --iso: using the median of a coarse whole-box grid, %.6g "
+            "(random weights have no zero level set)" % iso)
     torch.cuda.synchronize()
     t1 = time.time()
     verts, tris = pipe.run(feats, gfeat, trans_mat, FLAGS.sdf_res, iso, sdf_params)

@@ -83,6 +83,9 @@ class MeshPipeline:
         returns (verts[V,3] f64, tris[T,3] i32) device tensors on rank 0, (None, None) elsewhere."""
         ctx = self.ctx
         nz = res + 1
+        if self.world > res:
+            raise ValueError("z-slab sharding needs at least one voxel layer per rank: world=%d > sdf_res=%d"
+                             % (self.world, res))
         feats, gfeat = self._broadcast_features(feats, gfeat)
         ev = (lambda: self._mark()) if self.time_decode else (lambda: None)
         i0 = ev()
@@ -171,3 +174,10 @@ class MeshPipeline:
 def median_iso(sdf):
     """iso that guarantees a surface for random-init weights."""
     return float(torch.median(sdf.reshape(-1)).item())
+
+
+def coarse_median_iso(ctx, trans_mat, sdf_params=(-1, -1, -1, 1, 1, 1), res=32):
+    """Median of the SDF over a coarse (res+1)^3 grid spanning the WHOLE box (36 K points, one small
+    launch): the iso used with random-init weights, which have no zero level set.  It needs the image
+    to be set (ctx.set_image) and is the same number on every rank, whatever slab the rank owns."""
+    return median_iso(ctx.sdf_grid(trans_mat, res, sdf_params=sdf_params))

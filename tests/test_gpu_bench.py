@@ -26,3 +26,18 @@ def test_bench_line_schema():
     assert abs(d["value"] - 49 ** 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["mesh_matches_gpu"] is True and c["value"] > 0
+
+
+def test_bench_two_ranks():
+    """--gpus 2 with no launcher around it: bench.py starts two ranks itself (gloo here: both ranks share the one
+    GPU of the test box; RCCL needs one GPU per rank) and rank 0 reports n_gpus=2 on one z-slab-sharded grid."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["DISN_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--res", "40", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["sdf_res"] == 40 and d["config"]["points"] == 41 ** 3
+    assert d["config"]["mesh_triangles"] > 0 and d["scaling"] == "weak"

@@ -25,7 +25,10 @@ def test_batch_cli_layout_and_boxes(tmp_path):
     from disn_amd import create_sdf
     log_dir = str(tmp_path / "exp")
     assert create_sdf.main(["--img_feat_twostream", "--sdf_res", "24", "--synthetic", "3", "--log_dir", log_dir,
-                            "--store_dist"]) == 0
+                            "--store_dist", "--random_init"]) == 0
+    with pytest.raises(SystemExit) as e:      # no checkpoint and no --random_init: loud failure, nothing written
+        create_sdf.main(["--img_feat_twostream", "--sdf_res", "8", "--synthetic", "1", "--log_dir", str(tmp_path / "x")])
+    assert "no checkpoint" in str(e.value.code) and not os.path.exists(str(tmp_path / "x"))
     views = list(create_sdf.synthetic_views(3))
     root = create_sdf.result_obj_path(log_dir, 24, 0.0, False)
     for view in views:
