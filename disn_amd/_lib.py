@@ -40,6 +40,7 @@ SIGNATURES = {
     "disn_mc_emit": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "disn_mc_debug_info": (c_int, [c_void_p, c_void_p, c_void_p]),
     "disn_sort_triangles": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
+    "disn_sort_triangles_static": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
     "disn_write_dist": (c_int, [c_char_p, c_int, c_void_p, c_void_p]),
     "disn_read_dist_header": (c_int, [c_char_p, ctypes.POINTER(c_int), c_void_p]),
     "disn_read_dist": (c_int, [c_char_p, c_void_p, ctypes.c_size_t]),

@@ -188,11 +188,13 @@ class Context:
         self._check(self.lib.disn_mc_debug_info(self._h, out.data_ptr(), _stream()), "disn_mc_debug_info")
         return out
 
-    def sort_triangles(self, tris, max_index):
+    def sort_triangles(self, tris, max_index, static=False):
+        """In-place lexicographic sort; static=True takes the allocation-free entry point (<= 2^20 triangles)."""
         if not (tris.is_cuda and tris.dtype == torch.int32 and tris.is_contiguous()):
             raise DisnError("sort_triangles: need a contiguous CUDA int32 [n,3] tensor")
-        self._check(self.lib.disn_sort_triangles(self._h, tris.data_ptr(), tris.shape[0], max_index, _stream()),
-                    "disn_sort_triangles")
+        fn, name = ((self.lib.disn_sort_triangles_static, "disn_sort_triangles_static") if static else
+                    (self.lib.disn_sort_triangles, "disn_sort_triangles"))
+        self._check(fn(self._h, tris.data_ptr(), tris.shape[0], max_index, _stream()), name)
         return tris
 
 

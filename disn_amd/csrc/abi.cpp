@@ -9,6 +9,11 @@ extern "C" int disn_create(int device_id, DisnCtx** out) {
   if (hipSetDevice(device_id) != hipSuccess) return DISN_E_HIP;
   DisnCtx* c = new DisnCtx();
   c->device = device_id;
+  if (disn_mc_static_init(c) != DISN_OK) {   // per-device address of the allocation-free entry point's scratch
+    fprintf(stderr, "disn_create: %s\n", c->err.c_str());
+    delete c;
+    return DISN_E_HIP;
+  }
   *out = c;
   return DISN_OK;
 }

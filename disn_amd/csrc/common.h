@@ -23,6 +23,7 @@ struct DisnCtx {
   std::string err;
   SdfState* sdf = nullptr;
   McState* mc = nullptr;
+  void* static_scratch = nullptr;   // this device's copy of mc.hip's static scratch array (disn_mc_static_init)
 };
 
 inline int disn_fail(DisnCtx* ctx, int code, const char* fmt, ...) {
@@ -69,6 +70,7 @@ inline void disn_release(DevBuf& b) {
 
 void disn_sdf_state_free(DisnCtx*);
 void disn_mc_state_free(DisnCtx*);
+int disn_mc_static_init(DisnCtx*);   // mc.hip: looks up the device address of the static scratch array
 
 // ---- device helpers (wave = 64 lanes) ------------------------------------
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {

@@ -19,6 +19,7 @@
 #include <float.h>
 
 #include "common.h"
+#include <mutex>
 #include <type_traits>
 
 #define DISN_MC_QUAL __device__
@@ -813,17 +814,17 @@ extern "C" int disn_mc_count(DisnCtx* ctx, const float* sdf, const DisnMcGrid* g
   return DISN_OK;
 }
 
-static int sort_tris(DisnCtx* ctx, McState* m, int* tris, uint64_t n, uint64_t max_index, hipStream_t stream) {
+// the sort proper on caller-chosen scratch: tmp = n*3 ints, hist = (nb*256 + 256) unsigned.  Every scratch word
+// that is read has been written earlier in the same pass, so neither buffer needs to start at zero.
+static int sort_tris_on(DisnCtx* ctx, int* tris, uint64_t n, uint64_t max_index, int* tmp, unsigned* hist,
+                        hipStream_t stream) {
   if (n < 2) return DISN_OK;
   int bits = 1;
   while (bits < 32 && (max_index >> bits)) ++bits;
   const int passes = (bits + 7) / 8;
   const unsigned nb = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
-  DISN_TRY(disn_ensure(ctx, m->sort_tmp, n * 3 * sizeof(int)));
-  DISN_TRY(disn_ensure(ctx, m->sort_hist, ((size_t)nb * 256 + 256) * sizeof(unsigned)));
   int* a = tris;
-  int* b = (int*)m->sort_tmp.p;
-  unsigned* hist = (unsigned*)m->sort_hist.p;
+  int* b = tmp;
   for (int comp = 2; comp >= 0; --comp)
     for (int ps = 0; ps < passes; ++ps) {
       tri_sort_hist<<<nb, BLK, 0, stream>>>(a, n, comp, 8 * ps, hist, nb);
@@ -834,6 +835,61 @@ static int sort_tris(DisnCtx* ctx, McState* m, int* tris, uint64_t n, uint64_t m
   if (a != tris) DISN_HIP(ctx, hipMemcpyAsync(tris, a, n * 3 * sizeof(int), hipMemcpyDeviceToDevice, stream));
   DISN_HIP(ctx, hipGetLastError());
   return DISN_OK;
+}
+
+static int sort_tris(DisnCtx* ctx, McState* m, int* tris, uint64_t n, uint64_t max_index, hipStream_t stream) {
+  if (n < 2) return DISN_OK;
+  const unsigned nb = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+  DISN_TRY(disn_ensure(ctx, m->sort_tmp, n * 3 * sizeof(int)));
+  DISN_TRY(disn_ensure(ctx, m->sort_hist, ((size_t)nb * 256 + 256) * sizeof(unsigned)));
+  return sort_tris_on(ctx, tris, n, max_index, (int*)m->sort_tmp.p, (unsigned*)m->sort_hist.p, stream);
+}
+
+// ---- allocation-free triangle sort (disn_sort_triangles_static) ------------
+// For callers that cannot call hipMalloc (HIP graph capture, tight serving loops): the ping-pong buffer and the
+// digit histograms live in a file-scope device array instead of ctx-owned hipMalloc memory.  One copy of the
+// array exists per GPU the library runs on, at its own address, for the life of the process; `scratch` below is
+// only the host-side handle of the symbol -- the device address is taken once per device with
+// hipGetSymbolAddress (disn_mc_static_init, called by disn_create with that device current) and only that
+// pointer is ever handed to kernels or copies.
+constexpr uint64_t SORT_STATIC_MAX_TRIS = 1ull << 20;                                  // 1 Mi triangles
+constexpr unsigned SORT_STATIC_MAX_NB = (unsigned)(SORT_STATIC_MAX_TRIS / SORT_TILE);   // 512 sort tiles
+constexpr size_t SORT_STATIC_TMP_BYTES = SORT_STATIC_MAX_TRIS * 3 * sizeof(int);        // 12 MiB
+constexpr size_t SORT_STATIC_HIST_BYTES = ((size_t)SORT_STATIC_MAX_NB * 256 + 256) * sizeof(unsigned);
+static __device__ __align__(256) unsigned char scratch[SORT_STATIC_TMP_BYTES + SORT_STATIC_HIST_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[MAX_DEVICES];   // device address of `scratch` on each device, null until looked up
+
+int disn_mc_static_init(DisnCtx* ctx) {
+  if (ctx->device < 0 || ctx->device >= MAX_DEVICES)
+    return disn_fail(ctx, DISN_E_ARG, "device id %d outside the static scratch table", ctx->device);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[ctx->device]) {
+    DISN_HIP(ctx, hipSetDevice(ctx->device));
+    void* ptr = nullptr;
+    DISN_HIP(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return disn_fail(ctx, DISN_E_HIP, "hipGetSymbolAddress(scratch) returned null");
+    g_scratch_ptr[ctx->device] = ptr;
+  }
+  ctx->static_scratch = g_scratch_ptr[ctx->device];
+  return DISN_OK;
+}
+
+extern "C" int disn_sort_triangles_static(DisnCtx* ctx, int32_t* tris, uint64_t n, uint64_t max_index, void* stream_) {
+  if (!ctx) return DISN_E_ARG;
+  if (n && !tris) return disn_fail(ctx, DISN_E_ARG, "disn_sort_triangles_static: null buffer");
+  if (max_index >= (1ull << 31)) return disn_fail(ctx, DISN_E_ARG, "disn_sort_triangles_static: indices exceed int32");
+  if (n > SORT_STATIC_MAX_TRIS)
+    return disn_fail(ctx, DISN_E_ARG,
+                     "disn_sort_triangles_static: %llu triangles exceed the static scratch limit of %llu "
+                     "(use disn_sort_triangles, which allocates)",
+                     (unsigned long long)n, (unsigned long long)SORT_STATIC_MAX_TRIS);
+  if (!ctx->static_scratch) return disn_fail(ctx, DISN_E_STATE, "disn_sort_triangles_static: static scratch not initialised");
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned char* base = (unsigned char*)ctx->static_scratch;   // the device pointer, never the symbol
+  return sort_tris_on(ctx, tris, n, max_index, (int*)base, (unsigned*)(base + SORT_STATIC_TMP_BYTES), (hipStream_t)stream_);
 }
 
 extern "C" int disn_mc_emit(DisnCtx* ctx, const double* bbox, uint64_t centre_base, uint64_t edge_base, double* verts,

@@ -156,6 +156,15 @@ int disn_mc_debug_info(DisnCtx* ctx, uint16_t* out, void* stream);
  * (SURVEY.md App. B.6).  max_index bounds the values (limits radix passes). */
 int disn_sort_triangles(DisnCtx* ctx, int32_t* tris, uint64_t n, uint64_t max_index, void* stream);
 
+/* Allocation-free variant of disn_sort_triangles.  It has NO counterpart in the reference; it exists for
+ * callers that cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  Same arguments, same result (bit-identical order), but the sort's ping-pong buffer
+ * and histograms live in a static device array of the library (12.5 MiB per GPU, held until the process
+ * ends) instead of ctx-owned hipMalloc memory; the call itself performs no hipMalloc/hipFree.
+ * Limit: n <= 1 048 576 triangles (DISN_E_ARG beyond it).  All calls on one GPU share that GPU's array:
+ * calls that overlap in time on the same GPU (different streams / contexts / threads) race -- serialise them. */
+int disn_sort_triangles_static(DisnCtx* ctx, int32_t* tris, uint64_t n, uint64_t max_index, void* stream);
+
 /* ---- file formats (host) ----------------------------------------------- */
 /* .dist writer/reader.  Replaces to_binary (reference: demo/demo.py:342-353;
  * reader preprocessing/create_point_sdf_grid.py:29-51): int32 -res, res, res;
