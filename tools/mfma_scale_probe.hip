@@ -1,0 +1,399 @@
+// mfma_scale_probe.hip -- semantics and issue cost of the gfx950 block-scaled MFMA
+// (v_mfma_scale_f32_32x32x64_f8f6f4) beside the f16/bf16 32x32x16 forms (experiment, not product).
+//   part 1 (one wave): exact-integer checks of the operand maps, the E8M0 scale operands and the
+//                      f32 -> fp8 conversions the decoder would use;
+//   part 2 (256 workgroups x 4 waves, one wave per SIMD): shader cycles per instruction and wall
+//                      time of candidate inner loops on random operands.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/mfma_scale_probe tools/mfma_scale_probe.hip
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+typedef __attribute__((ext_vector_type(16))) float floatx16;
+typedef __attribute__((ext_vector_type(8))) int intx8;
+typedef __attribute__((ext_vector_type(6))) int intx6;
+typedef __attribute__((ext_vector_type(4))) int intx4;
+typedef __attribute__((ext_vector_type(8))) _Float16 halfx8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// ---- part 1: semantics ------------------------------------------------------
+// FMT: 0 fp8 e4m3, 2 fp6 e2m3, 4 fp4 e2m1 (cbsz / blgp encodings)
+template <int FA, int FB>
+__global__ void k_sem(const int* a, const int* b, const int* sa, const int* sb, float* d) {
+  const int lane = threadIdx.x;
+  intx8 av, bv;
+  for (int i = 0; i < 8; ++i) { av[i] = a[lane * 8 + i]; bv[i] = b[lane * 8 + i]; }
+  int s_a = sa[lane], s_b = sb[lane];
+  floatx16 acc;
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  if constexpr (FA == 0 && FB == 0)
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]\n\ts_nop 15\n\ts_nop 7"
+                 : "+v"(acc) : "v"(av), "v"(bv), "v"(s_a), "v"(s_b));
+  else if constexpr (FA == 2 && FB == 2) {
+    intx6 a6, b6;
+    for (int i = 0; i < 6; ++i) { a6[i] = av[i]; b6[i] = bv[i]; }
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2\n\ts_nop 15\n\ts_nop 7"
+                 : "+v"(acc) : "v"(a6), "v"(b6), "v"(s_a), "v"(s_b));
+  } else if constexpr (FA == 4 && FB == 4) {
+    intx4 a4, b4;
+    for (int i = 0; i < 4; ++i) { a4[i] = av[i]; b4[i] = bv[i]; }
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4\n\ts_nop 15\n\ts_nop 7"
+                 : "+v"(acc) : "v"(a4), "v"(b4), "v"(s_a), "v"(s_b));
+  } else if constexpr (FA == 2 && FB == 0) {   // fp6 weights x fp8 activations
+    intx6 a6;
+    for (int i = 0; i < 6; ++i) a6[i] = av[i];
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:0\n\ts_nop 15\n\ts_nop 7"
+                 : "+v"(acc) : "v"(a6), "v"(bv), "v"(s_a), "v"(s_b));
+  }
+  for (int i = 0; i < 16; ++i) d[lane * 16 + i] = acc[i];
+}
+
+// f32 -> fp8 conversions: plain, scaled; and the 32-wide fp6 conversion
+__global__ void k_cvt(const float* x, float scale, int* out_plain, int* out_scaled, int* out_fp6) {
+  const int lane = threadIdx.x;
+  float a = x[2 * lane], b = x[2 * lane + 1];
+  int r = 0;
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
+  out_plain[lane] = r;
+  typedef __attribute__((ext_vector_type(2))) short short2v;
+  short2v o = {0, 0};
+  o = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(o, a, b, scale, false);
+  out_scaled[lane] = (int)(unsigned short)o[0] | ((int)(unsigned short)o[1] << 16);
+  if (lane == 0) {
+    floatx16 lo, hi;
+    for (int i = 0; i < 16; ++i) { lo[i] = x[i]; hi[i] = x[16 + i]; }
+    intx6 p = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(lo, hi, scale);
+    for (int i = 0; i < 6; ++i) out_fp6[i] = p[i];
+  }
+}
+
+// the same conversions with MODE.FP16_OVFL = 1 (bit 23 of the MODE register): overflow should clamp to the
+// largest normal instead of producing NaN; plus the packed f32->f16 conversion and the f16-mix residual
+__global__ void k_cvt_ovfl(const float* x, float scale, int* out_plain, int* out_scaled, float* out_res, int* out_h) {
+  const int lane = threadIdx.x;
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
+  float a = x[2 * lane], b = x[2 * lane + 1];
+  int r = 0;
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
+  out_plain[lane] = r;
+  typedef __attribute__((ext_vector_type(2))) short short2v;
+  short2v o = {0, 0};
+  o = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(o, a, b, scale, false);
+  out_scaled[lane] = (int)(unsigned short)o[0] | ((int)(unsigned short)o[1] << 16);
+  int hp;
+  asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a), "v"(b));
+  out_h[lane] = hp;
+  float l0, l1;   // residuals a - f16(a), b - f16(b) with the f16 halves read in place
+  asm volatile("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hp), "v"(a));
+  asm volatile("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hp), "v"(b));
+  out_res[2 * lane] = l0;
+  out_res[2 * lane + 1] = l1;
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0");
+}
+
+static uint8_t enc_e4m3(float v) {   // exact for the small values used here (RNE otherwise), saturating
+  if (v == 0) return 0;
+  uint8_t s = v < 0 ? 0x80 : 0;
+  float a = fabsf(v);
+  if (a > 448) a = 448;
+  int e;
+  float m = frexpf(a, &e);           // a = m * 2^e, m in [0.5,1)
+  int E = e - 1 + 7;
+  if (E <= 0) {                      // subnormal: step 2^-9
+    int q = (int)lrintf(a * 512.0f);
+    if (q >= 8) return s | 0x08;
+    return s | (uint8_t)q;
+  }
+  int q = (int)lrintf((m * 2 - 1) * 8);
+  if (q == 8) { q = 0; ++E; }
+  if (E > 15 || (E == 15 && q == 7)) { E = 15; q = 6; }
+  return s | (uint8_t)(E << 3) | (uint8_t)q;
+}
+static float dec_e4m3(uint8_t b) {
+  int s = b >> 7, E = (b >> 3) & 15, q = b & 7;
+  float v = E == 0 ? q / 512.0f : ldexpf(1 + q / 8.0f, E - 7);
+  if (E == 15 && q == 7) v = NAN;
+  return s ? -v : v;
+}
+static uint8_t enc_e2m3(float v) {   // fp6: 1-2-3, bias 1, max 7.5
+  uint8_t s = v < 0 ? 0x20 : 0;
+  float a = fabsf(v);
+  if (a > 7.5f) a = 7.5f;
+  if (a < 1.0f) return s | (uint8_t)lrintf(a * 8);          // subnormal step 1/8 (8 -> E=1,q=0 has the same code)
+  int e = a >= 4 ? 2 : a >= 2 ? 1 : 0;
+  int q = (int)lrintf((a / (1 << e) - 1) * 8);
+  if (q == 8) { q = 0; ++e; }
+  if (e > 2) { e = 2; q = 7; }
+  return s | (uint8_t)((e + 1) << 3) | (uint8_t)q;
+}
+static float dec_e2m3(uint8_t b) {
+  int s = (b >> 5) & 1, E = (b >> 3) & 3, q = b & 7;
+  float v = E == 0 ? q / 8.0f : ldexpf(1 + q / 8.0f, E - 1);
+  return s ? -v : v;
+}
+static uint8_t enc_e2m1(float v) {   // fp4: 0 .5 1 1.5 2 3 4 6
+  static const float tab[8] = {0, .5f, 1, 1.5f, 2, 3, 4, 6};
+  uint8_t s = v < 0 ? 8 : 0;
+  float a = fabsf(v);
+  int best = 0;
+  for (int i = 1; i < 8; ++i) if (fabsf(tab[i] - a) < fabsf(tab[best] - a)) best = i;
+  return s | (uint8_t)best;
+}
+
+static void pack_bits(int* dst /*8 dwords*/, const uint8_t* codes, int bits) {   // element j at bit j*bits, little endian
+  memset(dst, 0, 32);
+  for (int j = 0; j < 32; ++j) {
+    int bit = j * bits;
+    uint64_t v = (uint64_t)codes[j] << (bit & 31);
+    dst[bit >> 5] |= (int)(uint32_t)v;
+    if ((bit & 31) + bits > 32) dst[(bit >> 5) + 1] |= (int)(uint32_t)(v >> 32);
+  }
+}
+
+template <int FA, int FB>
+static void run_sem(const char* name, int bits_a, int bits_b, int mode) {
+  // A[32][64], B[64][32] small values exact in every format; k = 32*h + j  (h = lane>>5, j = element in the lane)
+  std::vector<float> A(32 * 64), B(64 * 32);
+  srand(7 + mode);
+  const float vals8[] = {0, 1, -1, 2, -2, 3, 4, -6, 0.5f, 1.5f};
+  for (auto& v : A) v = vals8[rand() % 10];
+  for (auto& v : B) v = vals8[rand() % 10];
+  std::vector<int> a(64 * 8), b(64 * 8), sa(64), sb(64);
+  for (int lane = 0; lane < 64; ++lane) {
+    int r = lane & 31, h = lane >> 5;
+    uint8_t ca[32], cb[32];
+    for (int j = 0; j < 32; ++j) {
+      float va = A[r * 64 + 32 * h + j], vb = B[(32 * h + j) * 32 + r];
+      ca[j] = bits_a == 8 ? enc_e4m3(va) : bits_a == 6 ? enc_e2m3(va) : enc_e2m1(va);
+      cb[j] = bits_b == 8 ? enc_e4m3(vb) : bits_b == 6 ? enc_e2m3(vb) : enc_e2m1(vb);
+    }
+    pack_bits(&a[lane * 8], ca, bits_a);
+    pack_bits(&b[lane * 8], cb, bits_b);
+    // mode 0: both scales 1.0 (127); mode 1: scale_a depends on (row, half), scale_b = 2^-3; mode 2: scale in byte 1
+    sa[lane] = mode == 0 ? 127 : mode == 1 ? (127 + (r % 5) - 2 * h) : ((127 + 2) << 8) | 0x55;
+    sb[lane] = mode == 0 ? 127 : mode == 1 ? 124 : 127;
+  }
+  int *da, *db, *dsa, *dsb;
+  float* dd;
+  CK(hipMalloc(&da, a.size() * 4)); CK(hipMalloc(&db, b.size() * 4)); CK(hipMalloc(&dsa, 256)); CK(hipMalloc(&dsb, 256));
+  CK(hipMalloc(&dd, 64 * 16 * 4));
+  CK(hipMemcpy(da, a.data(), a.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dsa, sa.data(), 256, hipMemcpyHostToDevice)); CK(hipMemcpy(dsb, sb.data(), 256, hipMemcpyHostToDevice));
+  k_sem<FA, FB><<<1, 64>>>(da, db, dsa, dsb, dd);
+  CK(hipDeviceSynchronize());
+  std::vector<float> d(64 * 16);
+  CK(hipMemcpy(d.data(), dd, d.size() * 4, hipMemcpyDeviceToHost));
+  // hypotheses: H0 scale per (row, half h) applies to that half's 32 products; byte 0 of the scale register
+  int bad0 = 0, bad_b1 = 0;
+  double maxerr = 0;
+  for (int lane = 0; lane < 64; ++lane)
+    for (int g = 0; g < 16; ++g) {
+      int col = lane & 31, row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+      double want = 0, want_b1 = 0;
+      for (int h = 0; h < 2; ++h) {
+        double part = 0;
+        for (int j = 0; j < 32; ++j) part += (double)A[row * 64 + 32 * h + j] * B[(32 * h + j) * 32 + col];
+        int ea = sa[row + 32 * h] & 255, eb = sb[col + 32 * h] & 255;
+        int ea1 = (sa[row + 32 * h] >> 8) & 255;
+        want += part * ldexp(1.0, ea - 127) * ldexp(1.0, eb - 127);
+        want_b1 += part * ldexp(1.0, ea1 - 127) * ldexp(1.0, eb - 127);
+      }
+      double got = d[lane * 16 + g];
+      if (fabs(got - want) > 1e-3 * fmax(1.0, fabs(want))) ++bad0;
+      if (fabs(got - want_b1) > 1e-3 * fmax(1.0, fabs(want_b1))) ++bad_b1;
+      maxerr = fmax(maxerr, fabs(got - want));
+    }
+  printf("sem %-10s mode %d: mismatches vs byte0-scale hypothesis %4d / 1024 (max err %.3g); vs byte1 %4d\n", name, mode, bad0,
+         maxerr, bad_b1);
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dsa); (void)hipFree(dsb); (void)hipFree(dd);
+}
+
+static void run_cvt() {
+  std::vector<float> x(128);
+  const float pick[] = {0.f, 1.f, -1.f, 0.3f, 447.f, 449.f, 1000.f, -5000.f, 1e-3f, 2e-3f, 0.0137f, 3.3f, 100.f, 0.75f, 17.f, 6.2f};
+  for (int i = 0; i < 128; ++i) x[i] = pick[i % 16] * (i < 16 ? 1.f : (1 + i / 64.f));
+  float* dx; int *p, *s, *f6;
+  CK(hipMalloc(&dx, 512)); CK(hipMalloc(&p, 256)); CK(hipMalloc(&s, 256)); CK(hipMalloc(&f6, 32));
+  CK(hipMemcpy(dx, x.data(), 512, hipMemcpyHostToDevice));
+  const float scale = 4.0f;
+  k_cvt<<<1, 64>>>(dx, scale, p, s, f6);
+  CK(hipDeviceSynchronize());
+  int hp[64], hs[64], h6[8];
+  CK(hipMemcpy(hp, p, 256, hipMemcpyDeviceToHost)); CK(hipMemcpy(hs, s, 256, hipMemcpyDeviceToHost)); CK(hipMemcpy(h6, f6, 24, hipMemcpyDeviceToHost));
+  printf("cvt_pk_fp8_f32 / cvt_scalef32_pk_fp8_f32(scale=4):  x -> plain, scaled (decoded)\n");
+  for (int i = 0; i < 16; ++i) {
+    uint8_t bp = (hp[i / 2] >> (8 * (i & 1))) & 255, bs = (hs[i / 2] >> (8 * (i & 1))) & 255;
+    printf("  %10g -> %8g (0x%02x)   %8g (0x%02x)\n", x[i], dec_e4m3(bp), bp, dec_e4m3(bs), bs);
+  }
+  {
+    float* res; int* hh;
+    CK(hipMalloc(&res, 512)); CK(hipMalloc(&hh, 256));
+    k_cvt_ovfl<<<1, 64>>>(dx, scale, p, s, res, hh);
+    CK(hipDeviceSynchronize());
+    float hres[128]; int h16[64];
+    CK(hipMemcpy(hp, p, 256, hipMemcpyDeviceToHost)); CK(hipMemcpy(hs, s, 256, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hres, res, 512, hipMemcpyDeviceToHost)); CK(hipMemcpy(h16, hh, 256, hipMemcpyDeviceToHost));
+    printf("with MODE.FP16_OVFL=1:  x -> plain fp8, scaled fp8 (decoded), f16 bits, x - f16(x) by v_fma_mix_f32\n");
+    for (int i = 0; i < 16; ++i) {
+      uint8_t bp = (hp[i / 2] >> (8 * (i & 1))) & 255, bs = (hs[i / 2] >> (8 * (i & 1))) & 255;
+      unsigned short hb = (h16[i / 2] >> (16 * (i & 1))) & 0xffff;
+      _Float16 hv; memcpy(&hv, &hb, 2);
+      printf("  %10g -> %8g (0x%02x)   %8g (0x%02x)   f16 %10g   residual %12.5g (want %12.5g)\n", x[i], dec_e4m3(bp), bp,
+             dec_e4m3(bs), bs, (float)hv, hres[i], x[i] - (float)hv);
+    }
+  }
+  printf("cvt_scalef32_2xpk16_fp6_f32(scale=4) element order: ");
+  for (int j = 0; j < 32; ++j) {
+    int bit = 6 * j;
+    uint64_t w = (uint32_t)h6[bit >> 5] | ((uint64_t)(uint32_t)h6[(bit >> 5) + 1 < 6 ? (bit >> 5) + 1 : 5] << 32);
+    printf("%g ", dec_e2m3((w >> (bit & 31)) & 63));
+  }
+  printf("\n   inputs: ");
+  for (int j = 0; j < 32; ++j) printf("%g ", x[j]);
+  printf("\n");
+}
+
+// ---- part 2: issue cost --------------------------------------------------------
+#define M16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define MB16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define M8(acc, a, b, sa, sb) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+#define M8U(acc, a, b) asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define M6(acc, a, b, sa, sb) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+#define M4(acc, a, b, sa, sb) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+#define M68(acc, a, b, sa, sb) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:0" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+#define M48(acc, a, b, sa, sb) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:0" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+
+struct Res { long long cyc, wall; };
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k_cost(Res* out, const int* src, int rep) {
+  const int lane = threadIdx.x & 63;
+  intx8 a8[2], b8[2];
+  halfx8 ah[4], bh[4];
+  for (int q = 0; q < 2; ++q)
+    for (int i = 0; i < 8; ++i) {
+      a8[q][i] = src[(q * 8 + i) * 64 + lane] & 0x77777777;        // finite fp8 / fp6 / fp4 patterns, mixed signs off
+      b8[q][i] = src[(16 + q * 8 + i) * 64 + lane] & 0x77777777;
+    }
+  for (int q = 0; q < 4; ++q) {
+    intx4 ta, tb;
+    for (int i = 0; i < 4; ++i) { ta[i] = (src[(32 + q * 4 + i) * 64 + lane] & 0x3fff3fff) | 0x20002000; tb[i] = (src[(48 + q * 4 + i) * 64 + lane] & 0xbfffbfff) | 0x20002000; }
+    ah[q] = __builtin_bit_cast(halfx8, ta);
+    bh[q] = __builtin_bit_cast(halfx8, tb);
+  }
+  intx6 a6[2], b6[2];
+  intx4 a4[2], b4[2];
+  for (int q = 0; q < 2; ++q) {
+    for (int i = 0; i < 6; ++i) { a6[q][i] = a8[q][i]; b6[q][i] = b8[q][i]; }
+    for (int i = 0; i < 4; ++i) { a4[q][i] = a8[q][i]; b4[q][i] = b8[q][i]; }
+  }
+  int sa = 120, sb = 127;
+  floatx16 acc[4];
+  for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.001f * (i + e);
+  asm volatile("" : "+v"(sa), "+v"(sb));
+  long long w0 = wall_clock64();
+  long long t0 = clock64();
+#pragma unroll 1
+  for (int r = 0; r < rep; ++r) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      floatx16& c = acc[p & 3];
+      if constexpr (MODE == 0) { M16(c, ah[0], bh[0]); FENCE(); M16(c, ah[1], bh[1]); FENCE(); M16(c, ah[2], bh[2]); FENCE(); M16(c, ah[3], bh[3]); FENCE(); }
+      else if constexpr (MODE == 1) { bf16x8 x0 = __builtin_bit_cast(bf16x8, ah[0]), y0 = __builtin_bit_cast(bf16x8, bh[0]); MB16(c, x0, y0); FENCE(); MB16(c, x0, y0); FENCE(); MB16(c, x0, y0); FENCE(); MB16(c, x0, y0); FENCE(); }
+      else if constexpr (MODE == 2) { M8(c, a8[0], b8[0], sa, sb); FENCE(); M8(c, a8[1], b8[1], sa, sb); FENCE(); }
+      else if constexpr (MODE == 3) { M8U(c, a8[0], b8[0]); FENCE(); M8U(c, a8[1], b8[1]); FENCE(); }
+      else if constexpr (MODE == 4) { M6(c, a6[0], b6[0], sa, sb); FENCE(); M6(c, a6[1], b6[1], sa, sb); FENCE(); }
+      else if constexpr (MODE == 5) { M4(c, a4[0], b4[0], sa, sb); FENCE(); M4(c, a4[1], b4[1], sa, sb); FENCE(); }
+      else if constexpr (MODE == 6) { M68(c, a6[0], b8[0], sa, sb); FENCE(); M68(c, a6[1], b8[1], sa, sb); FENCE(); }
+      else if constexpr (MODE == 7) { M48(c, a4[0], b8[0], sa, sb); FENCE(); M48(c, a4[1], b8[1], sa, sb); FENCE(); }
+      else if constexpr (MODE == 8) {   // candidate group: 4 x f16 K16 + 2 x fp8 K64 (one 32-feature x 64-k block, 3-term split)
+        M16(c, ah[0], bh[0]); FENCE(); M16(c, ah[1], bh[1]); FENCE(); M16(c, ah[2], bh[2]); FENCE(); M16(c, ah[3], bh[3]); FENCE();
+        M8(c, a8[0], b8[0], sa, sb); FENCE(); M8(c, a8[1], b8[1], sa, sb); FENCE();
+      } else if constexpr (MODE == 9) {  // 4 x f16 + 2 x fp6
+        M16(c, ah[0], bh[0]); FENCE(); M16(c, ah[1], bh[1]); FENCE(); M16(c, ah[2], bh[2]); FENCE(); M16(c, ah[3], bh[3]); FENCE();
+        M6(c, a6[0], b6[0], sa, sb); FENCE(); M6(c, a6[1], b6[1], sa, sb); FENCE();
+      } else if constexpr (MODE == 10) {  // today's group: 12 x bf16 K16
+        bf16x8 x0 = __builtin_bit_cast(bf16x8, ah[0]), y0 = __builtin_bit_cast(bf16x8, bh[0]), x1 = __builtin_bit_cast(bf16x8, ah[1]), y1 = __builtin_bit_cast(bf16x8, bh[1]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { MB16(c, x0, y0); FENCE(); MB16(c, x1, y1); FENCE(); MB16(c, x0, y1); FENCE(); }
+      } else if constexpr (MODE == 12) {  // 4 x f16 + 2 x (fp4 weights x fp8 activations)
+        M16(c, ah[0], bh[0]); FENCE(); M16(c, ah[1], bh[1]); FENCE(); M16(c, ah[2], bh[2]); FENCE(); M16(c, ah[3], bh[3]); FENCE();
+        M48(c, a4[0], b8[0], sa, sb); FENCE(); M48(c, a4[1], b8[1], sa, sb); FENCE();
+      }
+    }
+  }
+  long long t1 = clock64();
+  long long w1 = wall_clock64();
+  float s = 0;
+  for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+  if (s == 12345.678f) out[0].cyc = 0;
+  if (lane == 0 && (threadIdx.x >> 6) == 0) { out[blockIdx.x].cyc = t1 - t0; out[blockIdx.x].wall = w1 - w0; }
+}
+
+template <int MODE>
+static void run_cost(const char* name, int insts_per_p, double kflop_per_p, const int* dsrc, Res* dres, int blocks) {
+  const int rep = 4000;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  k_cost<MODE><<<blocks, 256>>>(dres, dsrc, 200);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < 5; ++i) k_cost<MODE><<<blocks, 256>>>(dres, dsrc, rep);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= 5;
+  std::vector<Res> r(blocks);
+  CK(hipMemcpy(r.data(), dres, blocks * sizeof(Res), hipMemcpyDeviceToHost));
+  double cyc = 0, wall = 0;
+  for (auto& x : r) { cyc += x.cyc; wall += x.wall; }
+  cyc /= blocks; wall /= blocks;
+  const double per_p = cyc / (rep * 8.0);
+  const double ghz = cyc / (wall * 10.0) ;   // wall_clock64 ticks at 100 MHz
+  const double tflops = kflop_per_p * 1e3 * rep * 8.0 * 4 * blocks / (ms * 1e-3) / 1e12;
+  printf("cost %-34s blocks %3d: %7.1f cyc/group (%5.1f per inst), clock %.2f GHz, %.3f ms, %7.0f TFLOP/s (dense-equivalent of the group)\n",
+         name, blocks, per_p, per_p / insts_per_p, ghz, ms, tflops);
+}
+
+int main(int argc, char** argv) {
+  run_sem<0, 0>("fp8xfp8", 8, 8, 0);
+  run_sem<0, 0>("fp8xfp8", 8, 8, 1);
+  run_sem<0, 0>("fp8xfp8", 8, 8, 2);
+  run_sem<2, 2>("fp6xfp6", 6, 6, 0);
+  run_sem<2, 2>("fp6xfp6", 6, 6, 1);
+  run_sem<4, 4>("fp4xfp4", 4, 4, 0);
+  run_sem<4, 4>("fp4xfp4", 4, 4, 1);
+  run_sem<2, 0>("fp6xfp8", 6, 8, 1);
+  run_cvt();
+  std::vector<int> src(64 * 64);
+  srand(3);
+  for (auto& v : src) v = (rand() << 16) ^ rand();
+  int* dsrc; Res* dres;
+  CK(hipMalloc(&dsrc, src.size() * 4)); CK(hipMalloc(&dres, 1024 * sizeof(Res)));
+  CK(hipMemcpy(dsrc, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+  const double f16 = 2.0 * 32 * 32 * 16 / 1e3, f64k = 2.0 * 32 * 32 * 64 / 1e3;   // kFLOP per instruction
+  for (int blocks : {1, 256}) {
+    run_cost<0>("4 x f16 32x32x16", 4, 4 * f16, dsrc, dres, blocks);
+    run_cost<1>("4 x bf16 32x32x16", 4, 4 * f16, dsrc, dres, blocks);
+    run_cost<2>("2 x scaled fp8xfp8 32x32x64", 2, 2 * f64k, dsrc, dres, blocks);
+    run_cost<3>("2 x unscaled fp8xfp8 32x32x64", 2, 2 * f64k, dsrc, dres, blocks);
+    run_cost<4>("2 x scaled fp6xfp6", 2, 2 * f64k, dsrc, dres, blocks);
+    run_cost<5>("2 x scaled fp4xfp4", 2, 2 * f64k, dsrc, dres, blocks);
+    run_cost<6>("2 x scaled fp6(A) x fp8(B)", 2, 2 * f64k, dsrc, dres, blocks);
+    run_cost<7>("2 x scaled fp4(A) x fp8(B)", 2, 2 * f64k, dsrc, dres, blocks);
+    run_cost<10>("group today: 12 x bf16", 12, 4 * f16, dsrc, dres, blocks);
+    run_cost<8>("group A: 4 x f16 + 2 x fp8", 6, 4 * f16, dsrc, dres, blocks);
+    run_cost<9>("group B: 4 x f16 + 2 x fp6", 6, 4 * f16, dsrc, dres, blocks);
+    run_cost<12>("group C: 4 x f16 + 2 x fp4A.fp8B", 6, 4 * f16, dsrc, dres, blocks);
+  }
+  return 0;
+}
