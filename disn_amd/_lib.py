@@ -29,6 +29,7 @@ SIGNATURES = {
     "disn_last_error": (c_char_p, [c_void_p]),
     "disn_version": (c_char_p, []),
     "disn_sdf_set_weights": (c_int, [c_void_p, ctypes.POINTER(DisnDecoderWeights)]),
+    "disn_sdf_set_decoder": (c_int, [c_void_p, c_int]),
     "disn_sdf_set_image": (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
     "disn_sdf_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "disn_sdf_points": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

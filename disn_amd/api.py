@@ -80,6 +80,14 @@ class Context:
                     setattr(st, name, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
         self._check(self.lib.disn_sdf_set_weights(self._h, ctypes.byref(st)), "disn_sdf_set_weights")
 
+    DECODERS = {"mixed": 0, "bf16x3": 1}
+
+    def set_decoder(self, name):
+        """'mixed' (default: fp16 + fp8 residual products, bf16x3 last layer) or 'bf16x3' (every layer)."""
+        if name not in self.DECODERS:
+            raise DisnError("set_decoder: unknown decoder %r (have %s)" % (name, sorted(self.DECODERS)))
+        self._check(self.lib.disn_sdf_set_decoder(self._h, self.DECODERS[name]), "disn_sdf_set_decoder")
+
     def set_image(self, feat_maps, global_feat):
         """feat_maps: five NHWC/HWC float32 end points (conv1_2..conv5_3); global_feat: [1024]."""
         if len(feat_maps) != 5:

@@ -46,11 +46,13 @@ constexpr int LV_OFF[5] = {0, 64, 192, 448, 960};
 constexpr int SP_W1 = 0;      // [64][4] = w[0][f], w[1][f], w[2][f], b[f]
 constexpr int SP_B2 = 256;    // [256]
 constexpr int SP_B3 = 512;    // [512]
-constexpr int SP_B4 = 1024;   // [512] (global stream: includes the hoisted global-feature term)
-constexpr int SP_B5 = 1536;   // [256]
-constexpr int SP_W6 = 1792;   // [256]
-constexpr int SP_B6 = 2048;   // [1]
-constexpr int SP_SIZE = 2052;
+constexpr int SP_B5 = 1024;   // [256]
+constexpr int SP_W6 = 1280;   // [256]
+constexpr int SP_B6 = 1536;   // [1]
+constexpr int SP_SC = 1540;   // [3] (ints) E8M0 scale byte of the fp8 weight operands of fold1/conv2, fold1/conv3, fold2/conv1
+constexpr int SP_MX_LDS = 1544;   // the mixed-precision kernel keeps [0, SP_MX_LDS) in LDS and reads B4 from global memory
+constexpr int SP_B4 = 1544;   // [512] (global stream: includes the hoisted global-feature term)
+constexpr int SP_SIZE = 2056;
 
 // fragment pairs (hi 1 KiB + lo 1 KiB) per stream, in consumption order
 constexpr int PAIRS = 8 * 4 + 16 * (16 + 32) + 16 * 16;   // 1056 pairs = 2.06 MiB
@@ -696,18 +698,597 @@ __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
+// =====================================================================================================
+// Mixed-precision decoder ("mx", the default): fold1/conv2, fold1/conv3 and fold2/conv1 run as
+//     W.x  ~=  f16(W).f16(x)                      v_mfma_f32_32x32x16_f16            (1 unit of matrix time)
+//            + fp8(W - f16(W)).fp8(x)             v_mfma_scale_f32_32x32x64_f8f6f4   (0.5 units)
+//            + fp8(W).fp8(x - f16(x))             v_mfma_scale_f32_32x32x64_f8f6f4   (0.5 units)
+// instead of three bf16 products (3 units): the fp16 product leaves a 2^-12 relative residual on each operand,
+// and a correction that is itself good to 2^-4 (fp8 e4m3) brings the sum to ~2^-16, the accuracy of the bf16
+// triple (profiles/precision_budget.json).  The two residual products are block-scaled MFMAs at K = 64; their
+// power-of-two scales (per layer, chosen when the weights are packed) ride in the instruction's E8M0 scale
+// operands, so all three products accumulate into one fp32 accumulator.  fold2/conv2, whose input carries the
+// image / global feature term and dominates the error budget, stays on the bf16 triple.
+// Fragment stream, in 1 KiB UNITS (one ds_read_b128 per lane):  a "group" = 32 output features x 64 k =
+// 4 units f16(W) (k-steps of 16) + 2 units fp8 residual + 2 units fp8 W = 8 units = 8 KiB; a bf16 "pair" =
+// 2 units.  A stage = 32 units = 4 groups or 16 pairs.  The register ring holds 8 units; the slot an MFMA has
+// just consumed is refilled with the unit 8 further on.
+// MODE.FP16_OVFL is set for the kernel: f32->fp8/f16 conversions saturate (448 / 65504) instead of producing
+// NaN / inf, so an activation beyond fp8's range only loses its correction terms.
+typedef __attribute__((ext_vector_type(4))) int intx4;
+typedef __attribute__((ext_vector_type(8))) int intx8;
+typedef __attribute__((ext_vector_type(2))) short shortx2;
+
+constexpr int UNITS_PER_STAGE = 32;
+constexpr int XL_SHIFT = 11;    // x - f16(x) is scaled by 2^11 before its fp8 conversion (|x - f16(x)| * 2^11 <= x)
+
+// LDS of the mixed-precision kernel: ring | small parameters [2][SP_MX_LDS] | parked operands
+constexpr int MX_SP_BYTES = 2 * SP_MX_LDS * 4;
+constexpr int MX_PARK_BYTES_PER_WAVE = 4096;   // two 8-register operands (fp8 residuals of h2 groups 2, 3) per lane
+constexpr int MX_LDS_BYTES = NSLOT * STAGE_BYTES + MX_SP_BYTES + 4 * MX_PARK_BYTES_PER_WAVE;
+static_assert(MX_LDS_BYTES <= 160 * 1024, "LDS budget");
+
+struct Ring8 {
+  intx4 f[4];   // slots 0..3
+  intx8 e[2];   // slots 4,5 and 6,7 (one 8-register fp8 operand each)
+};
+
+// The B operands of one group of 64 input features for this wave's 32 points.  They are made IN PLACE out of the
+// two 32x32 fp32 accumulator blocks (a = features 0..31 of the group, b = 32..63) that hold the previous layer's
+// result: step i (0..7) reads a[i], a[8+i], b[i], b[8+i] and writes back
+//     a[i]   = f16 pair (a[i], a[8+i])       b[i]   = f16 pair (b[i], b[8+i])
+//     a[8+i] = fp8 x 4 of the four values    b[8+i] = fp8 x 4 of their f16 residuals * 2^11
+// so that afterwards a = [hi k-step 0 | hi k-step 1 | fp8(x) 8 regs], b = [hi k-step 2 | hi k-step 3 | fp8(x - f16 x)]
+// with no register beyond the accumulators themselves.  The resulting k order (which accumulator element sits in
+// which operand position) is matched by the weight packer: mx_hi_elem / mx_fp8_elem below.
+typedef __attribute__((ext_vector_type(16))) int intx16;
+struct XG {
+  intx16 a, b;   // fp32 accumulator bits before the split, operand bits after it
+};
+__device__ __forceinline__ intx16 as_bits(const floatx16& v) { return __builtin_bit_cast(intx16, v); }
+template <int S>
+__device__ __forceinline__ intx4 xg_hi(const XG& x) {   // f16(x), k-step S of 4
+  constexpr int o = 4 * (S & 1);
+  return S < 2 ? __builtin_shufflevector(x.a, x.a, o, o + 1, o + 2, o + 3)
+               : __builtin_shufflevector(x.b, x.b, o, o + 1, o + 2, o + 3);
+}
+__device__ __forceinline__ intx8 xg_x8(const XG& x) {
+  return __builtin_shufflevector(x.a, x.a, 8, 9, 10, 11, 12, 13, 14, 15);
+}
+__device__ __forceinline__ intx8 xg_xl8(const XG& x) {
+  return __builtin_shufflevector(x.b, x.b, 8, 9, 10, 11, 12, 13, 14, 15);
+}
+// accumulator element (block 0/1 = a/b, register g) behind operand positions; register g of a block <-> feature
+// 32*block + (g&3) + 8*(g>>2) + 4*h of the group (h = lane >> 5)
+__host__ __device__ constexpr int mx_hi_elem(int s, int j) {      // k-step s, element j -> 16*block + g
+  return 16 * (s >> 1) + 4 * (s & 1) + (j >> 1) + 8 * (j & 1);
+}
+__host__ __device__ constexpr int mx_fp8_elem(int byte) {         // byte 0..31 of the lane's fp8 operand -> 16*block + g
+  return 16 * ((byte >> 1) & 1) + (byte >> 2) + 8 * (byte & 1);
+}
+__host__ __device__ constexpr int mx_feature(int elem, int h) {   // -> feature 0..63 of the group
+  return 32 * (elem >> 4) + ((elem & 15) & 3) + 8 * ((elem & 15) >> 2) + 4 * h;
+}
+
+template <int S>
+__device__ __forceinline__ void ring_put(Ring8& rg, const uint4 v) {
+  if constexpr (S < 4) {
+    rg.f[S] = __builtin_bit_cast(intx4, v);
+  } else {
+    constexpr int q = (S - 4) >> 1, o = 4 * ((S - 4) & 1);
+    rg.e[q][o + 0] = (int)v.x; rg.e[q][o + 1] = (int)v.y; rg.e[q][o + 2] = (int)v.z; rg.e[q][o + 3] = (int)v.w;
+  }
+}
+template <int S>
+__device__ __forceinline__ intx4 ring_get(const Ring8& rg) {
+  if constexpr (S < 4) {
+    return rg.f[S];
+  } else {
+    constexpr int q = (S - 4) >> 1, o = 4 * ((S - 4) & 1);
+    return __builtin_shufflevector(rg.e[q], rg.e[q], o, o + 1, o + 2, o + 3);
+  }
+}
+
+// stage unit U (slot U & 7) has just been consumed: refill its slot with unit U + 8 and issue the LDS-DMA
+// piece that belongs to U (one 256 B piece per unit; the refill period runs from the middle of one stage to
+// the middle of the next, as in the bf16 kernel)
+template <int U>
+__device__ __forceinline__ void unit_read(Pipe& pipe, Ring8& rg) {
+  const uint4* src = (U + 8 < UNITS_PER_STAGE) ? pipe.cur + (U + 8) * 64 : pipe.nxt + (U + 8 - UNITS_PER_STAGE) * 64;
+  ring_put<U & 7>(rg, src[0]);
+  SCHED_FENCE();
+}
+// the pieces of a stage must be issued in ascending order: M0 moves to the second half after piece 15
+template <int U>
+__device__ __forceinline__ void unit_dma(Pipe& pipe) {
+  constexpr int J = (U + 16) & 31;
+  pipe.template dma_sub<J>();
+  if constexpr (J == 15) pipe.dma_hi();
+  SCHED_FENCE();
+}
+template <int U>
+__device__ __forceinline__ void unit_refill(Pipe& pipe, Ring8& rg) {
+  unit_read<U>(pipe, rg);
+  unit_dma<U>(pipe);
+}
+
+template <bool AGPR, bool LEAD>
+__device__ __forceinline__ void mfma_f16(floatx16& acc, const intx4& a, const intx4& b) {
+  if constexpr (AGPR) {
+    if constexpr (LEAD) asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  } else {
+    if constexpr (LEAD) asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  }
+}
+template <bool AGPR, bool LEAD>
+__device__ __forceinline__ void mfma_f16(intx16& acc, const intx4& a, const intx4& b) {   // accumulator held as bits (XG)
+  static_assert(!AGPR, "operand groups accumulate in VGPRs");
+  if constexpr (LEAD) asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// fp8 e4m3 x fp8 e4m3, K = 64, product scaled by 2^(sa-127) * 2^(sb-127) (byte 0 of the scale registers)
+template <bool AGPR>
+__device__ __forceinline__ void mfma_fp8(floatx16& acc, const intx8& a, const intx8& b, int sa, int sb) {
+  if constexpr (AGPR)
+    asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+a"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+  else
+    asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
+
+// Both residual products of a layer carry the same total scale: the weights are stored as fp8(W * 2^b) and
+// fp8((W - f16 W) * 2^(b + 11)), the activations as fp8(x) and fp8((x - f16 x) * 2^11), so either product needs
+// 2^-(b + 11): E8M0 bytes (127 - b) on the weight side and (127 - 11) on the activation side.
+template <bool AGPR>
+__device__ __forceinline__ void mfma_fp8(intx16& acc, const intx8& a, const intx8& b, int sa, int sb) {
+  static_assert(!AGPR, "operand groups accumulate in VGPRs");
+  asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
+__device__ __forceinline__ void drain_v(intx16& acc) { asm("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
+struct Scales {
+  int w;    // 127 - b of the layer
+  int xl;   // 127 - XL_SHIFT
+};
+
+// group G (0..3) of the current stage: six MFMAs into acc.  extra(gap<M>) runs in the shadow of MFMA M; the
+// shadows of the two K=64 MFMAs (M = 4, 5; 64 cycles each) are the ones with room for VALU work
+template <int G, bool AGPR, class Acc, class Extra>
+__device__ __forceinline__ void group_step_x(Pipe& pipe, Ring8& rg, Acc& acc, const XG& x, const intx8& xl8,
+                                             const Scales& sc, Extra extra);
+template <int G, bool AGPR, class Acc, class Extra>
+__device__ __forceinline__ void group_step(Pipe& pipe, Ring8& rg, Acc& acc, const XG& x, const Scales& sc, Extra extra) {
+  group_step_x<G, AGPR>(pipe, rg, acc, x, xg_xl8(x), sc, extra);
+}
+// the same with the fp8 residual operand given separately (it may have been parked in LDS)
+template <int G, bool AGPR, class Acc, class Extra>
+__device__ __forceinline__ void group_step_x(Pipe& pipe, Ring8& rg, Acc& acc, const XG& x, const intx8& xl8,
+                                             const Scales& sc, Extra extra) {
+  constexpr int U = 8 * G;
+  mfma_f16<AGPR, true>(acc, rg.f[0], xg_hi<0>(x));
+  SCHED_FENCE();
+  unit_refill<U + 0>(pipe, rg);
+  extra(gap<0>{});
+  SCHED_FENCE();
+  mfma_f16<AGPR, false>(acc, rg.f[1], xg_hi<1>(x));
+  SCHED_FENCE();
+  unit_refill<U + 1>(pipe, rg);
+  extra(gap<1>{});
+  SCHED_FENCE();
+  mfma_f16<AGPR, false>(acc, rg.f[2], xg_hi<2>(x));
+  SCHED_FENCE();
+  unit_refill<U + 2>(pipe, rg);
+  extra(gap<2>{});
+  SCHED_FENCE();
+  mfma_f16<AGPR, false>(acc, rg.f[3], xg_hi<3>(x));
+  SCHED_FENCE();
+  unit_refill<U + 3>(pipe, rg);
+  extra(gap<3>{});
+  SCHED_FENCE();
+#if defined(MX_DEBUG_E0_ZEROA)
+  { intx8 z = {0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("" : "+v"(z)); mfma_fp8<AGPR>(acc, z, xg_x8(x), sc.w, sc.xl); }
+#elif defined(MX_DEBUG_E0_ZEROB)
+  { intx8 z = {0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("" : "+v"(z)); mfma_fp8<AGPR>(acc, rg.e[0], z, sc.w, sc.xl); }
+#elif defined(MX_DEBUG_E0_BXL)
+  mfma_fp8<AGPR>(acc, rg.e[0], xl8, sc.w, sc.xl);
+#elif defined(MX_DEBUG_E0_AE1)
+  mfma_fp8<AGPR>(acc, rg.e[1], xg_x8(x), sc.w, sc.xl);
+#elif !defined(MX_DEBUG_NO_E0)
+  mfma_fp8<AGPR>(acc, rg.e[0], xg_x8(x), sc.w, sc.xl);
+#endif
+  SCHED_FENCE();
+  unit_refill<U + 4>(pipe, rg);
+  unit_refill<U + 5>(pipe, rg);
+  extra(gap<4>{});
+  SCHED_FENCE();
+#ifndef MX_DEBUG_NO_E1
+  mfma_fp8<AGPR>(acc, rg.e[1], xl8, sc.w, sc.xl);
+#endif
+  SCHED_FENCE();
+  unit_refill<U + 6>(pipe, rg);
+  unit_refill<U + 7>(pipe, rg);
+  if constexpr (G == 1) pipe.mid_sync();
+  extra(gap<5>{});
+  SCHED_FENCE();
+  if constexpr (G == 3) pipe.advance();
+}
+
+// bf16 pair P (0..15) of the current stage on the unit ring: units 2P (hi) and 2P+1 (lo)
+template <int P, bool AGPR, class Extra>
+__device__ __forceinline__ void pair_step8(Pipe& pipe, Ring8& rg, floatx16& acc, const bf16x8& xhi, const bf16x8& xlo,
+                                           Extra extra) {
+  constexpr int U = 2 * P;
+  const bf16x8 whi = __builtin_bit_cast(bf16x8, ring_get<U & 7>(rg));
+  const bf16x8 wlo = __builtin_bit_cast(bf16x8, ring_get<(U + 1) & 7>(rg));
+  mfma1<AGPR, true>(acc, wlo, xhi);
+  SCHED_FENCE();
+  unit_read<U + 1>(pipe, rg);
+  unit_dma<U>(pipe);
+  extra(gap<0>{});
+  SCHED_FENCE();
+  mfma1<AGPR, false>(acc, whi, xlo);
+  SCHED_FENCE();
+  extra(gap<1>{});
+  SCHED_FENCE();
+  mfma1<AGPR, false>(acc, whi, xhi);
+  SCHED_FENCE();
+  unit_read<U>(pipe, rg);
+  unit_dma<U + 1>(pipe);
+  if constexpr (P == 7) pipe.mid_sync();
+  extra(gap<2>{});
+  SCHED_FENCE();
+  if constexpr (P == 15) pipe.advance();
+}
+
+__device__ __forceinline__ int cvt_pk_f16(float a, float b) {   // round to nearest even, packed
+  int r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float res_lo(int hp, float a) {   // a - f16 in the low half of hp
+  float r;
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(a));
+  return r;
+}
+__device__ __forceinline__ float res_hi(int hp, float a) {   // a - f16 in the high half of hp
+  float r;
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(a));
+  return r;
+}
+
+// Packed f32 -> fp8 (e4m3) conversions into the low / high half of a register.  Inline asm on purpose: with the
+// builtins hipcc (ROCm 7.2) merged the low-half and the high-half conversion of one register into a single
+// instruction with the wrong sources when the value travelled through a vector element in between.
+__device__ __forceinline__ int fp8_lo(float a, float b) {          // bytes 0,1 (the upper half keeps whatever it held)
+  int r;
+  asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ int fp8_hi(int r, float a, float b) {   // bytes 2,3
+  asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2 op_sel:[0,0,1]" : "+v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ int fp8s_lo(float a, float b, float inv_scale) {   // fp8(a / inv_scale), fp8(b / inv_scale)
+  int r;
+  asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(inv_scale));
+  return r;
+}
+__device__ __forceinline__ int fp8s_hi(int r, float a, float b, float inv_scale) {
+  asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(r) : "v"(a), "v"(b), "s"(inv_scale));
+  return r;
+}
+// step I (0..7) of the in-place split of an accumulator pair (see XG), ReLU included; two parts of 7 VALU ops so
+// that it can be spread over MFMA shadows
+struct CvtMx {
+  int xl8;   // the half-written fp8 residual register between the two parts
+};
+constexpr float XL_INV_SCALE = 1.0f / (float)(1 << XL_SHIFT);
+template <int I>
+__device__ __forceinline__ void cvt_mx_a(XG& x, CvtMx& st) {   // the two elements of block a
+  const float r0 = relu1(__int_as_float(x.a[I])), r1 = relu1(__int_as_float(x.a[8 + I]));
+  const int hp = cvt_pk_f16(r0, r1);
+  const float l0 = res_lo(hp, r0), l1 = res_hi(hp, r1);
+  const int x8 = fp8_lo(r0, r1);
+  st.xl8 = fp8s_lo(l0, l1, XL_INV_SCALE);
+  x.a[I] = hp;
+  x.a[8 + I] = x8;   // upper half follows in part b
+}
+template <int I>
+__device__ __forceinline__ void cvt_mx_b(XG& x, CvtMx& st) {   // the two elements of block b
+  const float r0 = relu1(__int_as_float(x.b[I])), r1 = relu1(__int_as_float(x.b[8 + I]));
+  const int hp = cvt_pk_f16(r0, r1);
+  const float l0 = res_lo(hp, r0), l1 = res_hi(hp, r1);
+  const int x8 = fp8_hi(x.a[8 + I], r0, r1);
+  const int xl8 = fp8s_hi(st.xl8, l0, l1, XL_INV_SCALE);
+  x.b[I] = hp;
+  x.a[8 + I] = x8;
+  x.b[8 + I] = xl8;
+}
+__device__ __forceinline__ void cvt_mx_all(XG& x) {
+  static_for<8>([&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    CvtMx st;
+    cvt_mx_a<I>(x, st);
+    cvt_mx_b<I>(x, st);
+  });
+}
+
+__device__ __forceinline__ int load_scale(const float* sp, int layer) {
+  int w = ((const int*)(sp + SP_SC))[layer];
+  asm volatile("" : "+v"(w));   // the MFMA takes its scales from VGPRs
+  return w;
+}
+
+// one stage (4 groups) of fold1/conv3: K = 256 over the resident h2 into one 32-feature block.  The fp8 residual
+// operands of groups 2 and 3 are parked in LDS (park: this lane's slot) and fetched one group ahead of their use,
+// which takes 16 registers off the kernel's peak.
+__device__ __forceinline__ intx8 park_load(const uint4* park, int t) {
+  const uint4 lo = park[t * 128], hi = park[t * 128 + 64];
+  intx8 r;
+  r[0] = (int)lo.x; r[1] = (int)lo.y; r[2] = (int)lo.z; r[3] = (int)lo.w;
+  r[4] = (int)hi.x; r[5] = (int)hi.y; r[6] = (int)hi.z; r[7] = (int)hi.w;
+  return r;
+}
+__device__ __forceinline__ void park_store(uint4* park, int t, const XG& x) {
+  uint4 lo, hi;
+  lo.x = (unsigned)x.b[8]; lo.y = (unsigned)x.b[9]; lo.z = (unsigned)x.b[10]; lo.w = (unsigned)x.b[11];
+  hi.x = (unsigned)x.b[12]; hi.y = (unsigned)x.b[13]; hi.z = (unsigned)x.b[14]; hi.w = (unsigned)x.b[15];
+  park[t * 128] = lo;
+  park[t * 128 + 64] = hi;
+}
+template <class Tail>
+__device__ __forceinline__ void l3_stage_mx(Pipe& pipe, Ring8& rg, intx16& acc3, const XG (&h2)[4], const uint4* park,
+                                            const Scales& sc, Tail tail) {
+  intx8 p2, p3;
+  group_step<0, false>(pipe, rg, acc3, h2[0], sc, [](auto) {});
+  group_step<1, false>(pipe, rg, acc3, h2[1], sc, [&](auto mm) {
+    if constexpr (decltype(mm)::value == 1) p2 = park_load(park, 0);
+  });
+  group_step_x<2, false>(pipe, rg, acc3, h2[2], p2, sc, [&](auto mm) {
+    if constexpr (decltype(mm)::value == 1) p3 = park_load(park, 1);
+  });
+  group_step_x<3, false>(pipe, rg, acc3, h2[3], p3, sc, [&](auto mm) {
+    if constexpr (decltype(mm)::value == 4) tail();   // e.g. the bias of the next block, one long shadow ahead
+  });
+}
+
+__device__ __forceinline__ float stream_pass_mx(const bool LOCAL, Pipe& pipe, Ring8& rg, const float* sp,
+                                                const float* __restrict__ b4, uint4* park,
+                                                const float* __restrict__ pmap, float px, float py, float pz, float u,
+                                                float v) {
+  const int lane = pipe.lane, h = lane >> 5;
+  // fold2/conv1 accumulators: bias (+ image term), exactly as in the bf16 kernel
+  floatx16 acc4[16];
+  Corners cn;
+  if (LOCAL) {
+    asm volatile("" : "+v"(u), "+v"(v));
+    cn = corners(u, v);
+  }
+  if (LOCAL) {
+    floatx4 t[2][16];
+    auto gather = [&](floatx4 (&dst)[16], int nb4) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float* src = pmap + (size_t)cn.pix[c] * 512 + 32 * nb4 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[4 * c + q] = *(const floatx4*)(src + 8 * q);
+      }
+    };
+    gather(t[0], 0);
+    static_for<16>([&](auto nc) {
+      constexpr int nb4 = decltype(nc)::value;
+      if constexpr (nb4 + 1 < 16) gather(t[(nb4 + 1) & 1], nb4 + 1);
+      acc4[nb4] = bias_init(b4, 32 * nb4, h);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc4[nb4][4 * q + e] = fmaf(cn.w[c], t[nb4 & 1][4 * c + q][e], acc4[nb4][4 * q + e]);
+      asm volatile("" : "+a"(acc4[nb4]));
+    });
+  } else {
+#pragma unroll
+    for (int nb4 = 0; nb4 < 16; ++nb4) {
+      acc4[nb4] = bias_init(b4, 32 * nb4, h);
+      asm volatile("" : "+a"(acc4[nb4]));
+    }
+  }
+  int xl_scale = 127 - XL_SHIFT;
+  asm volatile("" : "+v"(xl_scale));
+  // fold1/conv1 (3 -> 64) on the VALU, laid out like two accumulator blocks and split in place
+  XG x1;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int f = (g & 3) + 8 * (g >> 2) + 4 * h;
+    floatx4 wa = *(const floatx4*)(sp + SP_W1 + 4 * f);
+    floatx4 wb = *(const floatx4*)(sp + SP_W1 + 4 * (32 + f));
+    x1.a[g] = __float_as_int(fmaf(pz, wa[2], fmaf(py, wa[1], px * wa[0])) + wa[3]);
+    x1.b[g] = __float_as_int(fmaf(pz, wb[2], fmaf(py, wb[1], px * wb[0])) + wb[3]);
+  }
+  cvt_mx_all(x1);
+  // fold1/conv2 (64 -> 256): 2 stages of 4 blocks (one group each); h2 stays resident as 4 operand groups
+  XG h2[4];
+  {
+    const Scales sc = {load_scale(sp, 0), xl_scale};
+    asm volatile("s_nop 7" ::: "memory");   // the split of h1 was written by VALU conversions just above
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      h2[2 * st].a = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 0), h));
+      h2[2 * st].b = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 1), h));
+      h2[2 * st + 1].a = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 2), h));
+      h2[2 * st + 1].b = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 3), h));
+      group_step<0, false>(pipe, rg, h2[2 * st].a, x1, sc, [](auto) {});
+      group_step<1, false>(pipe, rg, h2[2 * st].b, x1, sc, [](auto) {});
+      group_step<2, false>(pipe, rg, h2[2 * st + 1].a, x1, sc, [](auto) {});
+      group_step<3, false>(pipe, rg, h2[2 * st + 1].b, x1, sc, [](auto) {});
+      drain_v(h2[2 * st].b);
+      cvt_mx_all(h2[2 * st]);
+      drain_v(h2[2 * st + 1].b);
+      drain_v(h2[2 * st + 1].b);
+      cvt_mx_all(h2[2 * st + 1]);
+    }
+    park_store(park, 0, h2[2]);   // from here on b[8..15] of h2[2], h2[3] are dead in registers
+    park_store(park, 1, h2[3]);
+  }
+  // fold1/conv3 (256 -> 512) chained into fold2/conv1 in groups of 64 features: while group m of h3 feeds the
+  // sixteen fold2/conv1 accumulators (4 stages), blocks 2m+2, 2m+3 have already been accumulated (2 stages) and
+  // their in-place split fills the shadows of the K=64 MFMAs.
+  const Scales sc3 = {load_scale(sp, 1), xl_scale}, sc4 = {load_scale(sp, 2), xl_scale};
+  XG xc;
+  xc.a = as_bits(bias_init(sp + SP_B3, 0, h));
+  asm volatile("s_nop 7" ::: "memory");
+  l3_stage_mx(pipe, rg, xc.a, h2, park, sc3, [&] { xc.b = as_bits(bias_init(sp + SP_B3, 32, h)); });
+  l3_stage_mx(pipe, rg, xc.b, h2, park, sc3, [] {});
+  drain_v(xc.b);
+  drain_v(xc.b);
+  cvt_mx_all(xc);
+  asm volatile("s_nop 7" ::: "memory");
+  // fully unrolled, two operand sets in ping-pong (no copies, no loop-carried register constraints)
+  XG xd;
+  static_for<8>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    XG& cu = (m & 1) ? xd : xc;
+    XG& nx = (m & 1) ? xc : xd;
+    if constexpr (m < 7) {
+      nx.a = as_bits(bias_init(sp + SP_B3, 64 * m + 64, h));
+      l3_stage_mx(pipe, rg, nx.a, h2, park, sc3, [] {});
+      nx.b = as_bits(bias_init(sp + SP_B3, 64 * m + 96, h));
+      l3_stage_mx(pipe, rg, nx.b, h2, park, sc3, [] {});
+    }
+    CvtMx cs;
+    static_for<4>([&](auto sc_) {
+      constexpr int S = decltype(sc_)::value;
+      static_for<4>([&](auto gc) {
+        constexpr int G = decltype(gc)::value;
+        constexpr int T = 4 * S + G;          // group T of the phase: half a split step (T >> 1) in its last long shadow
+        group_step<G, true>(pipe, rg, acc4[T], cu, sc4, [&](auto mm) {
+          constexpr int M = decltype(mm)::value;
+          if constexpr (m < 7 && M == 5 && (T & 1) == 0) cvt_mx_a<(T >> 1)>(nx, cs);
+          if constexpr (m < 7 && M == 5 && (T & 1) == 1) cvt_mx_b<(T >> 1)>(nx, cs);
+        });
+      });
+    });
+  });
+  // fold2/conv2 (512 -> 256) on the bf16 triple, consuming the fold2/conv1 accumulators block by block
+  floatx16 acc5[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) acc5[nb] = bias_init(sp + SP_B5, 32 * nb, h);
+  bf16x8 yhi[2][2], ylo[2][2];
+  CvtState cs5;
+  drain_a(acc4[0]);
+#pragma unroll
+  for (int e = 0; e < 16; e += 2) cvt_pair(acc4[0], e, yhi[0], ylo[0]);
+  static_for<16>([&](auto nc) {
+    constexpr int nb4 = decltype(nc)::value;
+    constexpr int cur = nb4 & 1, nx = cur ^ 1, nn = nb4 < 15 ? nb4 + 1 : 15;
+    static_for<16>([&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      pair_step8<P, false>(pipe, rg, acc5[P >> 1], yhi[cur][P & 1], ylo[cur][P & 1], [&](auto mm) {
+        if constexpr (nb4 < 15 && decltype(mm)::value == 2) cvt_part<P>(acc4[nn], cs5, yhi[nx], ylo[nx]);
+      });
+    });
+  });
+  float part = 0.0f;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) {
+    drain_v(acc5[nb]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      floatx4 w = *(const floatx4*)(sp + SP_W6 + 32 * nb + 8 * q + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part = fmaf(fmaxf(acc5[nb][4 * q + e], 0.0f), w[e], part);
+    }
+  }
+  part += __shfl_xor(part, 32, 64);
+  return part + sp[SP_B6];
+}
+
+__global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");   // FP16_OVFL: saturating f16 / fp8 conversions
+  float* sp_lds = (float*)(lds + NSLOT * STAGE_BYTES);
+  for (int i = threadIdx.x; i < 2 * SP_MX_LDS; i += 256)
+    sp_lds[i] = a.sp[(i < SP_MX_LDS ? 0 : SP_SIZE - SP_MX_LDS) + i];   // both streams' blocks without their B4 tails
+  __syncthreads();
+  uint4* park = (uint4*)(lds + NSLOT * STAGE_BYTES + MX_SP_BYTES + (threadIdx.x >> 6) * MX_PARK_BYTES_PER_WAVE) + (threadIdx.x & 63);
+  const long long ntiles = (a.n + 127) / 128;
+  Pipe pipe;
+  pipe.ws = (const char*)a.ws;
+  pipe.ring = lds;
+  pipe.ring32 = (unsigned)(size_t)(lds_ptr_t)lds;
+  pipe.g = 0;
+  pipe.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  pipe.lane = threadIdx.x & 63;
+  pipe.voff = pipe.lane * 4;
+  pipe.dma_setup(0); pipe.dma_range<0, 16>(); pipe.dma_hi(); pipe.dma_range<16, 32>();
+  pipe.dma_setup(1); pipe.dma_range<0, 16>(); pipe.dma_hi(); pipe.dma_range<16, 32>();
+  pipe.dma_setup(2); pipe.dma_range<0, 16>(); pipe.dma_hi();   // second half: units 0..15 of stage 0
+  asm volatile("s_waitcnt vmcnt(48)" ::: "memory");   // stage 0 landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  pipe.cur = pipe.slot_ptr(0);
+  pipe.nxt = pipe.slot_ptr(1);
+  Ring8 rg;
+  static_for<8>([&](auto sc_) {
+    constexpr int S = decltype(sc_)::value;
+    ring_put<S>(rg, pipe.cur[S * 64]);
+  });
+  long long tile_first = blockIdx.x, tile_end = ntiles, tile_step = gridDim.x;
+  if ((gridDim.x & 7) == 0) {   // XCD-aware dealing, as in sdf_decode
+    const long long per = (ntiles + 7) / 8;
+    const int xcd = blockIdx.x & 7;
+    tile_first = xcd * per + (blockIdx.x >> 3);
+    tile_end = min(ntiles, (xcd + 1) * per);
+    tile_step = gridDim.x >> 3;
+  }
+  for (long long tile = tile_first; tile < tile_end; tile += tile_step) {
+    float pred = 0.0f;   // global stream first, then local: pred = g + l (reference models/model_normalization.py:204)
+#pragma unroll 1
+    for (int strm = 0; strm < 2; ++strm) {
+      // the point is recomputed for each stream instead of being carried through the first one in registers
+      long long p = tile * 128 + pipe.wave * 32 + (pipe.lane & 31);
+      if (p >= a.n) p = a.n - 1;
+      float x, y, z, xr, yr, zr;
+      if (a.grid_mode) {
+        const int n1 = a.res + 1;
+        int i = (int)(p % n1);
+        long long q = p / n1;
+        int j = (int)(q % n1);
+        int k = (int)(q / n1) + a.z0;
+        x = (float)(i == a.res ? a.hi[0] : __dadd_rn(__dmul_rn((double)i, a.step[0]), a.lo[0]));
+        y = (float)(j == a.res ? a.hi[1] : __dadd_rn(__dmul_rn((double)j, a.step[1]), a.lo[1]));
+        z = (float)(k == a.res ? a.hi[2] : __dadd_rn(__dmul_rn((double)k, a.step[2]), a.lo[2]));
+        xr = x; yr = y; zr = z;
+      } else {
+        x = a.pts[3 * p]; y = a.pts[3 * p + 1]; z = a.pts[3 * p + 2];
+        xr = a.pts_rot[3 * p]; yr = a.pts_rot[3 * p + 1]; zr = a.pts_rot[3 * p + 2];
+      }
+      float u, v;
+      project(a.T, x, y, z, u, v);
+      pred = __fadd_rn(pred, stream_pass_mx(strm != 0, pipe, rg, sp_lds + strm * SP_MX_LDS, a.sp + strm * SP_SIZE + SP_B4, park,
+                                               a.pmap, xr, yr, zr, u, v));
+    }
+    const long long p = tile * 128 + pipe.wave * 32 + (pipe.lane & 31);
+    if (p < a.n && pipe.lane < 32) a.out[p] = a.scale_out ? (float)((double)pred / 10.0) : pred;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 struct SdfState {
-  DevBuf ws, sp, f137, pmap, wimg, wglob, b4g, tmat;
+  DevBuf ws, wsmx, sp, f137, pmap, wimg, wglob, b4g, tmat;
   int num_cu = 256;
-  bool have_weights = false, have_image = false, lds_attr_set = false;
+  int decoder = DISN_DECODER_MIXED;
+  bool have_weights = false, have_image = false, lds_attr_set = false, lds_attr_set_mx = false;
 };
 
 void disn_sdf_state_free(DisnCtx* ctx) {
   if (!ctx->sdf) return;
   SdfState* s = ctx->sdf;
-  DevBuf* all[] = {&s->ws, &s->sp, &s->f137, &s->pmap, &s->wimg, &s->wglob, &s->b4g, &s->tmat};
+  DevBuf* all[] = {&s->ws, &s->wsmx, &s->sp, &s->f137, &s->pmap, &s->wimg, &s->wglob, &s->b4g, &s->tmat};
   for (DevBuf* b : all) disn_release(*b);
   delete s;
   ctx->sdf = nullptr;
@@ -756,6 +1337,70 @@ static void pack_pair(std::vector<uint16_t>& out, const float* W, int N, int nb,
   }
 }
 
+// ---- fragment stream of the mixed-precision kernel (units of 1 KiB, see sdf_decode_mx) ----------------
+static inline uint16_t f16_bits(float f) {
+  _Float16 h = (_Float16)f;   // round to nearest even
+  uint16_t b;
+  memcpy(&b, &h, 2);
+  return b;
+}
+static inline float f16_value(float f) { return (float)(_Float16)f; }
+// OCP fp8 e4m3 (bias 7, max 448, no infinities), round to nearest even, saturating
+static inline uint8_t e4m3_bits(float v) {
+  if (v != v) return 0x7f;
+  const uint8_t sgn = signbit(v) ? 0x80 : 0;
+  float a = fabsf(v);
+  if (a >= 448.0f) return sgn | 0x7e;
+  if (a < 0.015625f) {   // below 2^-6: subnormal, step 2^-9
+    int q = (int)nearbyintf(a * 512.0f);
+    return sgn | (uint8_t)q;   // q == 8 is the smallest normal, whose code is 0x08 as well
+  }
+  int e;
+  float m = frexpf(a, &e);   // a = m * 2^e, m in [0.5, 1)
+  int q = (int)nearbyintf((m * 2.0f - 1.0f) * 8.0f);
+  int E = e - 1 + 7;
+  if (q == 8) { q = 0; ++E; }
+  if (E > 15 || (E == 15 && q == 7)) return sgn | 0x7e;
+  return sgn | (uint8_t)(E << 3) | (uint8_t)q;
+}
+// largest power-of-two exponent a with maxabs * 2^a <= 448
+static inline int fp8_scale_exp(float maxabs) {
+  if (!(maxabs > 0.0f)) return 0;
+  int a = (int)floorf(log2f(448.0f / maxabs));
+  while (ldexpf(maxabs, a) > 448.0f) --a;
+  while (ldexpf(maxabs, a + 1) <= 448.0f) ++a;
+  return a < -100 ? -100 : a > 100 ? 100 : a;
+}
+// one group: 32 output features (block nb) x 64 input features (k group kg) of W[K][N]
+static void pack_group(std::vector<uint8_t>& out, const float* W, int N, int nb, int kg, int a_w) {
+  const size_t base = out.size();
+  out.resize(base + 8192);
+  uint8_t* o = out.data() + base;
+  for (int lane = 0; lane < 64; ++lane) {
+    const int r = lane & 31, h = lane >> 5;
+    for (int s = 0; s < 4; ++s)      // units 0..3: f16(W), k-step s; element j <-> the in-place operand order (XG)
+      for (int j = 0; j < 8; ++j) {
+        const int k = 64 * kg + mx_feature(mx_hi_elem(s, j), h);
+        const uint16_t b = f16_bits(W[(size_t)k * N + 32 * nb + r]);
+        memcpy(o + 1024 * s + lane * 16 + 2 * j, &b, 2);
+      }
+    for (int j = 0; j < 32; ++j) {   // units 4,5: fp8 of the f16 residual; units 6,7: fp8 of W; byte j of the lane's 32
+      const int k = 64 * kg + mx_feature(mx_fp8_elem(j), h);
+      const float w = W[(size_t)k * N + 32 * nb + r];
+      const float wl = w - f16_value(w);
+      o[4096 + 1024 * (j >> 4) + lane * 16 + (j & 15)] = e4m3_bits(ldexpf(wl, a_w + 11));   // |wl| <= 2^-11 |w|: no overflow
+      o[6144 + 1024 * (j >> 4) + lane * 16 + (j & 15)] = e4m3_bits(ldexpf(w, a_w));
+    }
+  }
+}
+// scale exponents of one layer: rows 0..K-1 of W[.][N]
+static void layer_scale(const float* W, int K, int N, int* a_w, float* maxabs) {
+  float mw = 0.0f;
+  for (size_t i = 0; i < (size_t)K * N; ++i) mw = fmaxf(mw, fabsf(W[i]));
+  *a_w = fp8_scale_exp(mw);
+  *maxabs = mw;
+}
+
 static int upload(DisnCtx* ctx, DevBuf& b, const void* src, size_t bytes) {
   DISN_TRY(disn_ensure(ctx, b, bytes));
   DISN_HIP(ctx, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
@@ -797,7 +1442,42 @@ extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
     DISN_TRY(disn_ensure(ctx, s->ws, (size_t)2 * PAIRS * 2048));
     DISN_HIP(ctx, hipMemcpy((char*)s->ws.p + (size_t)t * PAIRS * 2048, frag.data(), frag.size() * sizeof(uint16_t),
                             hipMemcpyHostToDevice));
+    // the same layers as units of the mixed-precision kernel: fold1/conv2, fold1/conv3, fold2/conv1 (point rows) as
+    // f16 + fp8 groups, fold2/conv2 as the bf16 pairs packed above
+    int sc_exp[3];
+    {
+      const float* lw[3] = {q.w2, q.w3, q.w4};
+      const int lk[3] = {64, 256, 512}, ln[3] = {256, 512, 512};
+      for (int l = 0; l < 3; ++l) {
+        float mx;
+        layer_scale(lw[l], lk[l], ln[l], &sc_exp[l], &mx);
+        if (!(mx < 65504.0f))
+          return disn_fail(ctx, DISN_E_ARG, "disn_sdf_set_weights: stream %d layer %d holds a non-finite weight or one beyond "
+                           "the fp16 range (max |w| = %g)", t, l, (double)mx);
+      }
+      std::vector<uint8_t> mxs;
+      mxs.reserve((size_t)PAIRS * 2048);
+      for (int nb2 = 0; nb2 < 8; ++nb2) pack_group(mxs, q.w2, 256, nb2, 0, sc_exp[0]);
+      for (int blk = 0; blk < 2; ++blk)
+        for (int kg = 0; kg < 4; ++kg) pack_group(mxs, q.w3, 512, blk, kg, sc_exp[1]);
+      for (int m = 0; m < 8; ++m) {
+        if (m < 7)
+          for (int blk = 2 * m + 2; blk < 2 * m + 4; ++blk)
+            for (int kg = 0; kg < 4; ++kg) pack_group(mxs, q.w3, 512, blk, kg, sc_exp[1]);
+        for (int nb4 = 0; nb4 < 16; ++nb4) pack_group(mxs, q.w4, 512, nb4, m, sc_exp[2]);
+      }
+      const size_t f2c2_pairs = 16 * 16;   // the tail of the bf16 stream: fold2/conv2
+      const uint8_t* tail = (const uint8_t*)frag.data() + ((size_t)PAIRS - f2c2_pairs) * 2048;
+      mxs.insert(mxs.end(), tail, tail + f2c2_pairs * 2048);
+      if (mxs.size() != (size_t)PAIRS * 2048) return disn_fail(ctx, DISN_E_STATE, "internal: mixed fragment stream size");
+      DISN_TRY(disn_ensure(ctx, s->wsmx, (size_t)2 * PAIRS * 2048));
+      DISN_HIP(ctx, hipMemcpy((char*)s->wsmx.p + (size_t)t * PAIRS * 2048, mxs.data(), mxs.size(), hipMemcpyHostToDevice));
+    }
     std::vector<float> sp(SP_SIZE, 0.0f);
+    for (int l = 0; l < 3; ++l) {
+      const int e8m0 = 127 - sc_exp[l];   // the MFMA multiplies the product by 2^(byte - 127)
+      memcpy(&sp[SP_SC + l], &e8m0, 4);
+    }
     for (int f = 0; f < 64; ++f) {
       sp[SP_W1 + 4 * f + 0] = q.w1[0 * 64 + f];
       sp[SP_W1 + 4 * f + 1] = q.w1[1 * 64 + f];
@@ -820,6 +1500,14 @@ extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
   DISN_TRY(upload(ctx, s->b4g, w->g_f2c1_b, 512 * sizeof(float)));
   s->have_weights = true;
   s->have_image = false;
+  return DISN_OK;
+}
+
+extern "C" int disn_sdf_set_decoder(DisnCtx* ctx, int decoder) {
+  if (!ctx) return DISN_E_ARG;
+  if (decoder != DISN_DECODER_MIXED && decoder != DISN_DECODER_BF16X3)
+    return disn_fail(ctx, DISN_E_ARG, "disn_sdf_set_decoder: unknown decoder %d", decoder);
+  sdf_state(ctx)->decoder = decoder;
   return DISN_OK;
 }
 
@@ -875,6 +1563,16 @@ static int launch_decode(DisnCtx* ctx, DecodeArgs& a, const float* trans_mat, hi
   const long long tiles = (a.n + 127) / 128;
   if (tiles * STAGES_PER_TILE > 0x7fffffffll) return disn_fail(ctx, DISN_E_ARG, "too many points for one launch");
   const unsigned blocks = (unsigned)(tiles < s->num_cu ? tiles : s->num_cu);
+  if (s->decoder == DISN_DECODER_MIXED) {
+    if (!s->lds_attr_set_mx) {
+      DISN_HIP(ctx, hipFuncSetAttribute((const void*)sdf_decode_mx, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));
+      s->lds_attr_set_mx = true;
+    }
+    a.ws = (const uint4*)s->wsmx.p;
+    sdf_decode_mx<<<blocks, 256, MX_LDS_BYTES, stream>>>(a);
+    DISN_HIP(ctx, hipGetLastError());
+    return DISN_OK;
+  }
   if (!s->lds_attr_set) {   // once per context (the attribute is per device and function)
     DISN_HIP(ctx, hipFuncSetAttribute((const void*)sdf_decode, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     s->lds_attr_set = true;

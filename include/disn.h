@@ -69,6 +69,18 @@ typedef struct DisnDecoderWeights {
  * (reference: demo/demo.py:153-165).  Host pointers; synchronous. */
 int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w);
 
+/* Arithmetic of the decoder's four MFMA layers (no counterpart in the reference, whose TF graph is plain fp32).
+ * Both stay within the 1e-4 tolerance on the SDF (profiles/precision_budget.json):
+ *   DISN_DECODER_MIXED  (default) fold1/conv2, fold1/conv3, fold2/conv1: fp16 product + two fp8 (e4m3, K=64,
+ *                       block-scaled MFMA) residual products; fold2/conv2: three bf16 products.
+ *                       Activations of the first three layers beyond 448 lose their residual terms
+ *                       (conversions saturate); weights must lie inside the fp16 range.
+ *   DISN_DECODER_BF16X3 three bf16 products (hi/lo split of both operands) in every layer: 1.33x the matrix time.
+ * Takes effect at the next disn_sdf_grid / disn_sdf_points. */
+#define DISN_DECODER_MIXED 0
+#define DISN_DECODER_BF16X3 1
+int disn_sdf_set_decoder(DisnCtx* ctx, int decoder);
+
 /* Per-image constants.  feat_maps = the five VGG end points conv1_2, conv2_2,
  * conv3_3, conv4_3, conv5_3 as DEVICE fp32 NHWC at native resolution
  * [224,224,64] [112,112,128] [56,56,256] [28,28,512] [14,14,512];

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Build-time check of the generated decoder kernels (called by disn_amd/csrc/Makefile).
+
+The decoders keep the LDS-DMA base in M0 across asm statements and count their own `s_waitcnt vmcnt(N)` over the
+LDS-DMA pieces they issue.  Both assumptions hold only while, between the first and the last MFMA of a stream,
+  * hipcc never touches M0 (only our `s_mov_b32 m0, sN`),
+  * hipcc emits no vector-memory instruction of its own: no scratch spill/reload, no global/buffer load or store
+    (each would shift the hand-counted vmcnt, and its own wait would be computed without our LDS-DMA pieces).
+Outside that region (point set-up and Pmap gather before the first MFMA, the result store after the last) the
+compiler's own memory instructions are fine.  Fails the build otherwise."""
+import re
+import sys
+
+
+def kernel_text(asm, name):
+    m = re.search(r"^(_ZN\S*%s\S*):" % name, asm, re.M)
+    if not m:
+        sys.exit("check_decode_asm: kernel %s not found" % name)
+    end = asm.find("s_endpgm", m.end())
+    return asm[m.end():end].split("\n")
+
+
+def check(asm, name):
+    lines = kernel_text(asm, name)
+    code = [l.split(";")[0].strip() for l in lines]
+    mf = [i for i, l in enumerate(code) if l.startswith("v_mfma")]
+    if not mf:
+        sys.exit("check_decode_asm: no MFMA in %s" % name)
+    first, last = mf[0], mf[-1]
+    bad = []
+    for i, l in enumerate(code):
+        if re.search(r"\bm0\b", l) and not re.fullmatch(r"s_mov_b32 m0, s\d+", l):
+            bad.append((i, "M0 used by the compiler: " + l))
+        if first < i < last:
+            if l.startswith(("scratch_", "buffer_", "global_store", "flat_")) or \
+               (l.startswith("global_load") and not l.startswith("global_load_lds_dword")):
+                bad.append((i, "compiler memory instruction inside the pipelined region: " + l))
+    if bad:
+        for i, msg in bad[:20]:
+            print("check_decode_asm: %s line %d: %s" % (name, i, msg))
+        sys.exit(1)
+    n_dma = sum(l.startswith("global_load_lds_dword") for l in code)
+    print("check_decode_asm: %s ok (%d MFMAs, %d LDS-DMA pieces, %d lines)" % (name, len(mf), n_dma, len(code)))
+
+
+if __name__ == "__main__":
+    text = open(sys.argv[1]).read()
+    for k in sys.argv[2:]:
+        check(text, k)

@@ -261,6 +261,87 @@ static void run_cvt() {
   printf("\n");
 }
 
+// ---- part 1b: a dependent chain of four f16 K=16 MFMAs and two scaled fp8 K=64 MFMAs on ONE accumulator, back to
+// back (NOPS = 0) or with the accumulator drained between them (NOPS = 1): does the hardware order the mixed chain?
+template <int NOPS>
+__global__ void k_chain(const int* ah, const int* bh, const int* a8, const int* b8, float* d) {
+  const int lane = threadIdx.x;
+  intx4 fa[4], fb[4];
+  intx8 ea[2], eb[2];
+  for (int q = 0; q < 4; ++q)
+    for (int i = 0; i < 4; ++i) { fa[q][i] = ah[(q * 64 + lane) * 4 + i]; fb[q][i] = bh[(q * 64 + lane) * 4 + i]; }
+  for (int q = 0; q < 2; ++q)
+    for (int i = 0; i < 8; ++i) { ea[q][i] = a8[(q * 64 + lane) * 8 + i]; eb[q][i] = b8[(q * 64 + lane) * 8 + i]; }
+  int s1 = 125, s2 = 128;
+  floatx16 acc;
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  asm volatile("s_nop 7" : "+v"(acc), "+v"(s1), "+v"(s2));
+#define PAD() do { if (NOPS) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc)); } while (0)
+  for (int rep = 0; rep < 2; ++rep) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fa[0]), "v"(fb[0])); PAD();
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fa[1]), "v"(fb[1])); PAD();
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fa[2]), "v"(fb[2])); PAD();
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fa[3]), "v"(fb[3])); PAD();
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(ea[0]), "v"(eb[0]), "v"(s1), "v"(s2)); PAD();
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(ea[1]), "v"(eb[1]), "v"(s2), "v"(s1)); PAD();
+  }
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc));
+  for (int i = 0; i < 16; ++i) d[lane * 16 + i] = acc[i];
+}
+
+static void run_chain() {
+  srand(11);
+  std::vector<int> ah(4 * 64 * 4), bh(4 * 64 * 4), a8(2 * 64 * 8), b8(2 * 64 * 8);
+  // values: small integers (exact in f16, e4m3 and in the fp32 sums)
+  std::vector<float> Af(4 * 32 * 16), Bf(4 * 16 * 32), A8(2 * 32 * 64), B8(2 * 64 * 32);
+  for (auto& v : Af) v = (float)(rand() % 9 - 4);
+  for (auto& v : Bf) v = (float)(rand() % 9 - 4);
+  for (auto& v : A8) v = (float)(rand() % 9 - 4);
+  for (auto& v : B8) v = (float)(rand() % 9 - 4);
+  for (int q = 0; q < 4; ++q)
+    for (int lane = 0; lane < 64; ++lane) {
+      int r = lane & 31, h = lane >> 5;
+      for (int j = 0; j < 8; ++j) {
+        _Float16 x = (_Float16)Af[(q * 32 + r) * 16 + 8 * h + j], y = (_Float16)Bf[(q * 16 + 8 * h + j) * 32 + r];
+        unsigned short xb, yb; memcpy(&xb, &x, 2); memcpy(&yb, &y, 2);
+        int& da = ah[(q * 64 + lane) * 4 + j / 2]; int& db = bh[(q * 64 + lane) * 4 + j / 2];
+        if (j & 1) { da |= (int)xb << 16; db |= (int)yb << 16; } else { da = xb; db = yb; }
+      }
+    }
+  for (int q = 0; q < 2; ++q)
+    for (int lane = 0; lane < 64; ++lane) {
+      int r = lane & 31, h = lane >> 5;
+      uint8_t ca[32], cb[32];
+      for (int j = 0; j < 32; ++j) { ca[j] = enc_e4m3(A8[(q * 32 + r) * 64 + 32 * h + j]); cb[j] = enc_e4m3(B8[(q * 64 + 32 * h + j) * 32 + r]); }
+      pack_bits(&a8[(q * 64 + lane) * 8], ca, 8);
+      pack_bits(&b8[(q * 64 + lane) * 8], cb, 8);
+    }
+  int *dah, *dbh, *da8, *db8; float* dd;
+  CK(hipMalloc(&dah, ah.size() * 4)); CK(hipMalloc(&dbh, bh.size() * 4)); CK(hipMalloc(&da8, a8.size() * 4)); CK(hipMalloc(&db8, b8.size() * 4));
+  CK(hipMalloc(&dd, 64 * 16 * 4));
+  CK(hipMemcpy(dah, ah.data(), ah.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dbh, bh.data(), bh.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(da8, a8.data(), a8.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db8, b8.data(), b8.size() * 4, hipMemcpyHostToDevice));
+  for (int nops = 0; nops < 2; ++nops) {
+    if (nops) k_chain<1><<<1, 64>>>(dah, dbh, da8, db8, dd); else k_chain<0><<<1, 64>>>(dah, dbh, da8, db8, dd);
+    CK(hipDeviceSynchronize());
+    std::vector<float> d(64 * 16);
+    CK(hipMemcpy(d.data(), dd, d.size() * 4, hipMemcpyDeviceToHost));
+    int bad = 0; double maxerr = 0;
+    for (int lane = 0; lane < 64; ++lane)
+      for (int g = 0; g < 16; ++g) {
+        int col = lane & 31, row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+        double want = 0;
+        for (int q = 0; q < 4; ++q) for (int k = 0; k < 16; ++k) want += (double)Af[(q * 32 + row) * 16 + k] * Bf[(q * 16 + k) * 32 + col];
+        for (int q = 0; q < 2; ++q) { double p = 0; for (int k = 0; k < 64; ++k) p += (double)A8[(q * 32 + row) * 64 + k] * B8[(q * 64 + k) * 32 + col]; want += p * 0.5; }   // 2^(125-127) * 2^(128-127)
+        want *= 2;
+        double got = d[lane * 16 + g];
+        if (fabs(got - want) > 1e-3) ++bad;
+        maxerr = fmax(maxerr, fabs(got - want));
+      }
+    printf("chain 2 x (4 f16 + 2 fp8) on one accumulator, %s: mismatches %d / 1024 (max err %.3g)\n", nops ? "drained between MFMAs" : "back to back", bad, maxerr);
+  }
+}
+
 // ---- part 2: issue cost --------------------------------------------------------
 #define M16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define MB16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
@@ -374,6 +455,8 @@ int main(int argc, char** argv) {
   run_sem<4, 4>("fp4xfp4", 4, 4, 1);
   run_sem<2, 0>("fp6xfp8", 6, 8, 1);
   run_cvt();
+  run_chain();
+  if (argc > 1) return 0;
   std::vector<int> src(64 * 64);
   srand(3);
   for (auto& v : src) v = (rand() << 16) ^ rand();

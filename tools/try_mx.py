@@ -1,0 +1,48 @@
+"""Development check of the mixed-precision decoder against the oracle (float64) and the bf16x3 decoder:
+accuracy on random points, then interleaved timing of both at sdf_res 256.  GPU only."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from disn_amd import synth, _lib
+if os.environ.get("TRY_LIB"):
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ["TRY_LIB"])
+from disn_amd.api import Context
+from oracle import net
+
+ctx = Context(0)
+maps, gf = net.synthetic_features(seed=3)
+w16 = {k: (v.astype(np.float16).astype(np.float32) if k.endswith("_w") else v) for k, v in synth.decoder_weights(seed=0).items()}
+for name, w in (("xavier0", synth.decoder_weights(seed=0)), ("xavier0_f16w", w16), ("xavier1+bias", net.xavier_decoder_weights(1, bias_scale=1.0))):
+    ctx.set_weights(w)
+    ctx.set_image(maps, gf)
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-1, 1, size=(4096 + 77, 3)).astype(np.float32)
+    ref = net.sdf_points(pts, pts, synth.GT_TRANS_MAT, maps, gf, w, dtype=torch.float64)
+    for dec in ("bf16x3", "mixed"):
+        ctx.set_decoder(dec)
+        got = ctx.sdf_points(synth.GT_TRANS_MAT, pts).cpu().numpy()
+        torch.cuda.synchronize()
+        err = np.abs(got - ref)
+        print("%-14s %-7s max |err| raw %.3e (after /10: %.3e), nan %d, max |ref| %.3f" %
+              (name, dec, err.max(), err.max() / 10, int(np.isnan(got).sum()), np.abs(ref).max()), flush=True)
+        if dec == "mixed" and err.max() > 1e-3:
+            bad = np.argsort(-err)[:8]
+            print("   worst idx", bad, "got", got[bad], "ref", ref[bad])
+if len(sys.argv) > 1:
+    res = int(sys.argv[1])
+    out = torch.empty((res + 1, res + 1, res + 1), dtype=torch.float32, device=ctx.device)
+    for rnd in range(3):
+        for dec in ("bf16x3", "mixed"):
+            ctx.set_decoder(dec)
+            ctx.sdf_grid(synth.GT_TRANS_MAT, res, out=out)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                ctx.sdf_grid(synth.GT_TRANS_MAT, res, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            print("round %d %-7s sdf_res %d: %.2f ms per grid" % (rnd, dec, res, e0.elapsed_time(e1) / 3), flush=True)
+ctx.close()
