@@ -158,6 +158,7 @@ __global__ void k_sample_features(const float* __restrict__ f137, const float* _
 // v_mfma_f32_32x32x2_f32.  128x128 tile per workgroup, 4 waves of 64x64.
 constexpr int GT = 128, GK = 16;
 __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, const float* __restrict__ B,
+                                                   const float* __restrict__ bias /*[N], added to every row*/,
                                                    float* __restrict__ C, int M, int N, int K) {
   __shared__ float As[GK][GT + 4];
   __shared__ float Bs[GK][GT + 4];
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, c
       for (int g = 0; g < 16; ++g) {
         int row = m0 + wm + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
         int col = n0 + wn + b * 32 + r;
-        if (row < M) C[(size_t)row * N + col] = acc[a][b][g];
+        if (row < M) C[(size_t)row * N + col] = __fadd_rn(acc[a][b][g], bias[col]);
       }
 }
 
@@ -486,9 +487,13 @@ __device__ __forceinline__ float stream_pass(const bool LOCAL, Pipe& pipe, Frags
     static_for<16>([&](auto nc) {
       constexpr int nb4 = decltype(nc)::value;
       if constexpr (nb4 + 1 < 16) gather(t[(nb4 + 1) & 1], nb4 + 1);
-      acc4[nb4] = bias_init(sp + SP_B4, 32 * nb4, h);
+      // the blend of the four corners (fold2/conv1's bias was added to the map by disn_sdf_set_image)
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc4[nb4][4 * q + e] = cn.w[0] * t[nb4 & 1][q][e];
+#pragma unroll
+      for (int c = 1; c < 4; ++c)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -722,8 +727,8 @@ typedef __attribute__((ext_vector_type(2))) short shortx2;
 constexpr int UNITS_PER_STAGE = 32;
 constexpr int XL_SHIFT = 11;    // x - f16(x) is scaled by 2^11 before its fp8 conversion (|x - f16(x)| * 2^11 <= x)
 
-// LDS of the mixed-precision kernel: ring | small parameters [2][SP_MX_LDS] | parked operands
-constexpr int MX_SP_BYTES = 2 * SP_MX_LDS * 4;
+// LDS of the mixed-precision kernel: ring | small parameters [2][SP_MX_LDS] | B4 of the global stream [512] | parked operands
+constexpr int MX_SP_BYTES = (2 * SP_MX_LDS + 512) * 4;
 constexpr int MX_PARK_BYTES_PER_WAVE = 4096;   // two 8-register operands (fp8 residuals of h2 groups 2, 3) per lane
 constexpr int MX_LDS_BYTES = NSLOT * STAGE_BYTES + MX_SP_BYTES + 4 * MX_PARK_BYTES_PER_WAVE;
 static_assert(MX_LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -928,12 +933,12 @@ __device__ __forceinline__ void pair_step8(Pipe& pipe, Ring8& rg, floatx16& acc,
   SCHED_FENCE();
   mfma1<AGPR, false>(acc, whi, xlo);
   SCHED_FENCE();
+  unit_dma<U + 1>(pipe);
   extra(gap<1>{});
   SCHED_FENCE();
   mfma1<AGPR, false>(acc, whi, xhi);
   SCHED_FENCE();
   unit_read<U>(pipe, rg);
-  unit_dma<U + 1>(pipe);
   if constexpr (P == 7) pipe.mid_sync();
   extra(gap<2>{});
   SCHED_FENCE();
@@ -1053,7 +1058,7 @@ __device__ __forceinline__ void l3_stage_mx(Pipe& pipe, Ring8& rg, intx16& acc3,
 }
 
 __device__ __forceinline__ float stream_pass_mx(const bool LOCAL, Pipe& pipe, Ring8& rg, const float* sp,
-                                                const float* __restrict__ b4, uint4* park,
+                                                const float* b4 /*LDS: global stream's fold2/conv1 bias*/, uint4* park,
                                                 const float* __restrict__ pmap, float px, float py, float pz, float u,
                                                 float v) {
   const int lane = pipe.lane, h = lane >> 5;
@@ -1078,9 +1083,13 @@ __device__ __forceinline__ float stream_pass_mx(const bool LOCAL, Pipe& pipe, Ri
     static_for<16>([&](auto nc) {
       constexpr int nb4 = decltype(nc)::value;
       if constexpr (nb4 + 1 < 16) gather(t[(nb4 + 1) & 1], nb4 + 1);
-      acc4[nb4] = bias_init(b4, 32 * nb4, h);
+      // the blend of the four corners (fold2/conv1's bias was added to the map by disn_sdf_set_image)
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc4[nb4][4 * q + e] = cn.w[0] * t[nb4 & 1][q][e];
+#pragma unroll
+      for (int c = 1; c < 4; ++c)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1145,13 +1154,13 @@ __device__ __forceinline__ float stream_pass_mx(const bool LOCAL, Pipe& pipe, Ri
   drain_v(xc.b);
   cvt_mx_all(xc);
   asm volatile("s_nop 7" ::: "memory");
-  // fully unrolled, two operand sets in ping-pong (no copies, no loop-carried register constraints)
+  // Two operand sets in ping-pong.  The chain is a loop of three double steps (m = 0..5) plus a tail (m = 6, 7)
+  // so that the hot code stays small: straight-line code that misses the instruction cache ran 25-40 % slower
+  // per stage than the same stages inside a loop.
   XG xd;
-  static_for<8>([&](auto mc) {
-    constexpr int m = decltype(mc)::value;
-    XG& cu = (m & 1) ? xd : xc;
-    XG& nx = (m & 1) ? xc : xd;
-    if constexpr (m < 7) {
+  auto chain = [&](XG& cu, XG& nx, const int m, auto with_next) {
+    constexpr bool NEXT = decltype(with_next)::value;
+    if constexpr (NEXT) {
       nx.a = as_bits(bias_init(sp + SP_B3, 64 * m + 64, h));
       l3_stage_mx(pipe, rg, nx.a, h2, park, sc3, [] {});
       nx.b = as_bits(bias_init(sp + SP_B3, 64 * m + 96, h));
@@ -1165,13 +1174,21 @@ __device__ __forceinline__ float stream_pass_mx(const bool LOCAL, Pipe& pipe, Ri
         constexpr int T = 4 * S + G;          // group T of the phase: half a split step (T >> 1) in its last long shadow
         group_step<G, true>(pipe, rg, acc4[T], cu, sc4, [&](auto mm) {
           constexpr int M = decltype(mm)::value;
-          if constexpr (m < 7 && M == 5 && (T & 1) == 0) cvt_mx_a<(T >> 1)>(nx, cs);
-          if constexpr (m < 7 && M == 5 && (T & 1) == 1) cvt_mx_b<(T >> 1)>(nx, cs);
+          if constexpr (NEXT && M == 5 && (T & 1) == 0) cvt_mx_a<(T >> 1)>(nx, cs);
+          if constexpr (NEXT && M == 5 && (T & 1) == 1) cvt_mx_b<(T >> 1)>(nx, cs);
         });
       });
     });
-  });
-  // fold2/conv2 (512 -> 256) on the bf16 triple, consuming the fold2/conv1 accumulators block by block
+  };
+#pragma unroll 1
+  for (int mm = 0; mm < 3; ++mm) {
+    chain(xc, xd, 2 * mm, std::true_type{});
+    chain(xd, xc, 2 * mm + 1, std::true_type{});
+  }
+  chain(xc, xd, 6, std::true_type{});
+  chain(xd, xc, 7, std::false_type{});
+  // fold2/conv2 (512 -> 256) on the bf16 triple, consuming the fold2/conv1 accumulators block by block (unrolled:
+  // the accumulator file cannot be indexed by a loop counter)
   floatx16 acc5[8];
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) acc5[nb] = bias_init(sp + SP_B5, 32 * nb, h);
@@ -1211,6 +1228,7 @@ __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
   float* sp_lds = (float*)(lds + NSLOT * STAGE_BYTES);
   for (int i = threadIdx.x; i < 2 * SP_MX_LDS; i += 256)
     sp_lds[i] = a.sp[(i < SP_MX_LDS ? 0 : SP_SIZE - SP_MX_LDS) + i];   // both streams' blocks without their B4 tails
+  for (int i = threadIdx.x; i < 512; i += 256) sp_lds[2 * SP_MX_LDS + i] = a.sp[SP_B4 + i];   // global stream's B4 (+ hoisted term)
   __syncthreads();
   uint4* park = (uint4*)(lds + NSLOT * STAGE_BYTES + MX_SP_BYTES + (threadIdx.x >> 6) * MX_PARK_BYTES_PER_WAVE) + (threadIdx.x & 63);
   const long long ntiles = (a.n + 127) / 128;
@@ -1252,13 +1270,15 @@ __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
       if (p >= a.n) p = a.n - 1;
       float x, y, z, xr, yr, zr;
       if (a.grid_mode) {
-        const int n1 = a.res + 1;
-        int i = (int)(p % n1);
-        long long q = p / n1;
-        int j = (int)(q % n1);
-        int k = (int)(q / n1) + a.z0;
-        x = (float)(i == a.res ? a.hi[0] : __dadd_rn(__dmul_rn((double)i, a.step[0]), a.lo[0]));
-        y = (float)(j == a.res ? a.hi[1] : __dadd_rn(__dmul_rn((double)j, a.step[1]), a.lo[1]));
+        // p -> (i, j, k) without 64-bit integer division: the plane index by an (exact) double division,
+        // the rest in 32 bits (a plane has at most 2048^2 points)
+        const unsigned n1 = (unsigned)a.res + 1u, plane = n1 * n1;
+        const unsigned kz = (unsigned)((double)p / (double)plane);
+        const unsigned rem = (unsigned)(p - (long long)kz * plane);
+        const unsigned j = rem / n1, i = rem - j * n1;
+        const int k = (int)kz + a.z0;
+        x = (float)((int)i == a.res ? a.hi[0] : __dadd_rn(__dmul_rn((double)i, a.step[0]), a.lo[0]));
+        y = (float)((int)j == a.res ? a.hi[1] : __dadd_rn(__dmul_rn((double)j, a.step[1]), a.lo[1]));
         z = (float)(k == a.res ? a.hi[2] : __dadd_rn(__dmul_rn((double)k, a.step[2]), a.lo[2]));
         xr = x; yr = y; zr = z;
       } else {
@@ -1267,7 +1287,7 @@ __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
       }
       float u, v;
       project(a.T, x, y, z, u, v);
-      pred = __fadd_rn(pred, stream_pass_mx(strm != 0, pipe, rg, sp_lds + strm * SP_MX_LDS, a.sp + strm * SP_SIZE + SP_B4, park,
+      pred = __fadd_rn(pred, stream_pass_mx(strm != 0, pipe, rg, sp_lds + strm * SP_MX_LDS, sp_lds + 2 * SP_MX_LDS, park,
                                                a.pmap, xr, yr, zr, u, v));
     }
     const long long p = tile * 128 + pipe.wave * 32 + (pipe.lane & 31);
@@ -1279,7 +1299,7 @@ __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
 }  // namespace
 
 struct SdfState {
-  DevBuf ws, wsmx, sp, f137, pmap, wimg, wglob, b4g, tmat;
+  DevBuf ws, wsmx, sp, f137, pmap, wimg, wglob, b4g, b4l, tmat;
   int num_cu = 256;
   int decoder = DISN_DECODER_MIXED;
   bool have_weights = false, have_image = false, lds_attr_set = false, lds_attr_set_mx = false;
@@ -1288,7 +1308,7 @@ struct SdfState {
 void disn_sdf_state_free(DisnCtx* ctx) {
   if (!ctx->sdf) return;
   SdfState* s = ctx->sdf;
-  DevBuf* all[] = {&s->ws, &s->wsmx, &s->sp, &s->f137, &s->pmap, &s->wimg, &s->wglob, &s->b4g, &s->tmat};
+  DevBuf* all[] = {&s->ws, &s->wsmx, &s->sp, &s->f137, &s->pmap, &s->wimg, &s->wglob, &s->b4g, &s->b4l, &s->tmat};
   for (DevBuf* b : all) disn_release(*b);
   delete s;
   ctx->sdf = nullptr;
@@ -1498,6 +1518,7 @@ extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
   DISN_TRY(upload(ctx, s->wglob, w->g_f2c1_w + (size_t)512 * 512, (size_t)1024 * 512 * sizeof(float)));
   DISN_TRY(upload(ctx, s->wimg, w->l_f2c1_w + (size_t)512 * 512, (size_t)FEAT_C * 512 * sizeof(float)));
   DISN_TRY(upload(ctx, s->b4g, w->g_f2c1_b, 512 * sizeof(float)));
+  DISN_TRY(upload(ctx, s->b4l, w->l_f2c1_b, 512 * sizeof(float)));   // folded into Pmap by disn_sdf_set_image
   s->have_weights = true;
   s->have_image = false;
   return DISN_OK;
@@ -1541,7 +1562,7 @@ extern "C" int disn_sdf_set_image(DisnCtx* ctx, const float* const feat_maps[5],
                                                               (float*)s->f137.p, IMG, IMG, FEAT_C, LV_OFF[l]);
   }
   dim3 grid(512 / GT, (NPIX + GT - 1) / GT);
-  k_gemm_f32<<<grid, 256, 0, stream>>>((const float*)s->f137.p, (const float*)s->wimg.p, (float*)s->pmap.p, NPIX, 512,
+  k_gemm_f32<<<grid, 256, 0, stream>>>((const float*)s->f137.p, (const float*)s->wimg.p, (const float*)s->b4l.p, (float*)s->pmap.p, NPIX, 512,
                                        FEAT_C);
   k_global_bias<<<2, 256, 0, stream>>>(global_feat, (const float*)s->wglob.p, (const float*)s->b4g.p,
                                        (float*)s->sp.p + SP_B4);

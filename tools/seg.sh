@@ -17,4 +17,4 @@ open(p, 'w').write(s)
 PY
 make -s -C disn_amd/csrc SKIP_CHECK=1 2>&1 | grep -i error || true
 grep -c scratch_ disn_amd/csrc/.temps/sdf-hip-amdgcn-amd-amdhsa-gfx950.s || true
-gpurun --timeout 600 -- 'timeout -k 10 200 python tools/seg_probe.py' 2>&1 | tail -10
+gpurun --timeout 600 -- "timeout -k 10 200 python ${SEGPROBE:-tools/seg_probe.py}" 2>&1 | tail -10

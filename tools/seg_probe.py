@@ -7,6 +7,7 @@ from disn_amd.api import Context
 from disn_amd.encoder import Vgg16Encoder
 ctx = Context(0)
 ctx.set_weights(synth.decoder_weights(seed=0))
+ctx.set_decoder("bf16x3")
 enc = Vgg16Encoder(ctx, synth.vgg_weights(seed=0))
 g, f = enc(synth.image(seed=0))
 ctx.set_image(f, g)
