@@ -26,7 +26,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALG_FLOP_PER_POINT = 3671808        # SURVEY.md s8d (global term hoisted)
-MFMA_FLOP_PER_POINT = 3 * 2 * 2 * (64 * 256 + 256 * 512 + 512 * 512 + 512 * 256)   # executed bf16 MFMA flops (3-product split)
+# MFMA pipe time per point in bf16-rate flops (2 streams x 2 flop/MAC): the bf16x3 decoder runs 3 bf16 products per
+# layer; the mixed decoder 1 f16 product + 2 fp8 products at twice the rate (= 2 units) on fold1/conv2, fold1/conv3
+# and fold2/conv1, and the bf16 triple on fold2/conv2
+_L123, _L4 = 64 * 256 + 256 * 512 + 512 * 512, 512 * 256
+MFMA_FLOP_PER_POINT = {"bf16x3": 2 * 2 * 3 * (_L123 + _L4), "mixed": 2 * 2 * (2 * _L123 + 3 * _L4)}
+DTYPE = {"bf16x3": "f32 (bf16x3 split MFMA, f32 accumulate)",
+         "mixed": "f32 (f16 + 2 block-scaled fp8 residual MFMAs on three layers, bf16x3 on fold2/conv2; f32 accumulate)"}
 PEAK_BF16_TFLOPS = 2500.0           # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -85,6 +91,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--res", type=int, default=0, help="sdf_res (default 256 at N=1, round(256*N^(1/3)) otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decoder", choices=("mixed", "bf16x3"), default="mixed",
+                    help="decoder arithmetic (disn_sdf_set_decoder); both meet the 1e-4 parity tolerance")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -115,6 +123,7 @@ def main():
 
     res = args.res or (256 if world == 1 else int(round(256 * world ** (1.0 / 3.0))))
     ctx = Context(local_rank)
+    ctx.set_decoder(args.decoder)
     weights = synth.decoder_weights(seed=0)
     ctx.set_weights(weights)
     enc = Vgg16Encoder(ctx, synth.vgg_weights(seed=0))
@@ -162,21 +171,21 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         alg_tflops = local_pts * ALG_FLOP_PER_POINT / (dec_ms * 1e-3) / 1e12
-        mfma_tflops = local_pts * MFMA_FLOP_PER_POINT / (dec_ms * 1e-3) / 1e12
+        mfma_tflops = local_pts * MFMA_FLOP_PER_POINT[args.decoder] / (dec_ms * 1e-3) / 1e12
         out = {
             "metric": "SDF query points/sec (node), ms per mesh incl. marching cubes",
             "value": points / (dt / args.steps), "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (bf16x3 split MFMA, f32 accumulate)", "data": "synthetic",
+            "dtype": DTYPE[args.decoder], "data": "synthetic",
             "config": {"workload": "sdf_res=%d two-stream, full sorted mesh output, %d z-slab(s)" % (res, world),
-                       "sdf_res": res, "points": points, "mesh_vertices": int(verts.shape[0]),
+                       "sdf_res": res, "decoder": args.decoder, "points": points, "mesh_vertices": int(verts.shape[0]),
                        "mesh_triangles": int(tris.shape[0]), "iso": iso,
                        "per_gpu_points_evaluated": local_pts, "halo": pipe.halo if world > 1 else None},
-            "roofline": {"bound": "mfma", "kernel": "sdf_decode", "achieved": alg_tflops, "peak": PEAK_BF16_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "sdf_decode_mx" if args.decoder == "mixed" else "sdf_decode", "achieved": alg_tflops, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": alg_tflops / PEAK_BF16_TFLOPS, "traffic": None,
                          "kernel_ms": dec_ms, "alg_flop_per_point": ALG_FLOP_PER_POINT,
-                         "executed_mfma_tflops": mfma_tflops, "mfma_issue_frac": mfma_tflops / PEAK_BF16_TFLOPS},
+                         "executed_mfma_tflops_bf16_rate": mfma_tflops, "mfma_issue_frac": mfma_tflops / PEAK_BF16_TFLOPS},
         }
         if world == 1 and pipe.mc_events:
             # the HBM-bound parts: marching cubes against its algorithmic bytes

@@ -234,11 +234,85 @@ struct DecodeArgs {
   const float* pts;         // points mode: projection input [n][3]
   const float* pts_rot;     // points mode: decoder input [n][3]
   long long n;
-  int grid_mode, res, z0;   // grid mode: point p -> (i,j,k+z0) of a (res+1)^3 grid
+  int grid_mode, res, z0;   // grid mode: planes z0.. of a (res+1)^3 grid; tile -> points by grid_point()
+  long long ntiles;         // tiles of 128 points
+  // grid mode: the "core" [0,ic) x [0,jc) x [0,kc) (multiples of 8, 4, 4) is cut into bricks of 8 x 4 x 4 points,
+  // one tile each; bricks are ordered in super-bricks of 2^sbi x 2^sbj x 2^sbk bricks; the rest of the slab
+  // (three boxes r1, r2, r3) is enumerated linearly after the core tiles
+  int n1, nk, ic, jc, kc, sbi, sbj, sbk, nsi, nsj;
+  long long core_tiles;
+  unsigned r1, r2, r3;      // points in the remainder boxes k >= kc, (k < kc, j >= jc), (k < kc, j < jc, i >= ic)
   double lo[3], hi[3], step[3];
   int scale_out;            // 1: out = float(double(pred)/10)  (reference demo/demo.py:335,351)
   float* out;
 };
+
+// Per-launch geometry, copied to LDS by the kernels: kept out of the scalar registers on purpose (the decoders run
+// at the register limit, and kernel arguments that stay live across a tile cost spills).
+struct Geom {
+  double lo[3], hi[3], step[3];
+  float T[12];
+  int res, z0, n1, ic, jc, kc, sbi, sbj, sbk, nsi, nsj, core_tiles;
+  unsigned r1, r2, r3;
+};
+constexpr int GEOM_BYTES = 192;
+static_assert(sizeof(Geom) <= GEOM_BYTES, "Geom block");
+__device__ __forceinline__ void geom_store(Geom* g, const DecodeArgs& a) {
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < 3; ++q) { g->lo[q] = a.lo[q]; g->hi[q] = a.hi[q]; g->step[q] = a.step[q]; }
+    for (int q = 0; q < 12; ++q) g->T[q] = a.T[q];
+    g->res = a.res; g->z0 = a.z0; g->n1 = a.n1; g->ic = a.ic; g->jc = a.jc; g->kc = a.kc;
+    g->sbi = a.sbi; g->sbj = a.sbj; g->sbk = a.sbk; g->nsi = a.nsi; g->nsj = a.nsj; g->core_tiles = (int)a.core_tiles;
+    g->r1 = a.r1; g->r2 = a.r2; g->r3 = a.r3;
+  }
+}
+
+// Grid mode: point (i, j, k) (k relative to z0) of lane `l32` (0..31) of wave `wave` in tile `tile`.
+// A wave's 32 points are an 8 x 4 block of one plane (32-byte runs of the output): their projections share pixel
+// corners (~7 distinct pixel rows per gather instruction instead of ~12 for 32 consecutive points of a grid line),
+// and the 32 CUs of an XCD, which take
+// consecutive tiles, work inside one 32^3 super-brick whose pixel rows stay in that XCD's L2 -- walking whole
+// planes re-fetched the 38 MB pixel map from HBM for every plane.  Returns false for the padding of the last tile.
+__device__ __forceinline__ bool grid_point(const Geom* g, unsigned t, int wave, int l32, int& i, int& j, int& k) {
+  const unsigned core = (unsigned)g->core_tiles;
+  if (t < core) {
+    const unsigned sbi = g->sbi, sbj = g->sbj, sbk = g->sbk, nsi = g->nsi, nsj = g->nsj;
+    const unsigned w = t & ((1u << (sbi + sbj + sbk)) - 1u), sidx = t >> (sbi + sbj + sbk);
+    const unsigned li = w & ((1u << sbi) - 1u), lj = (w >> sbi) & ((1u << sbj) - 1u), lk = w >> (sbi + sbj);
+    const unsigned s2 = sidx / nsi, si = sidx - s2 * nsi;
+    const unsigned sk = s2 / nsj, sj = s2 - sk * nsj;
+    i = (int)(8u * ((si << sbi) + li)) + (l32 & 7);
+    j = (int)(4u * ((sj << sbj) + lj)) + (l32 >> 3);
+    k = (int)(4u * ((sk << sbk) + lk)) + wave;
+    return true;
+  }
+  const unsigned n1 = (unsigned)g->n1, ic = g->ic, jc = g->jc, kc = g->kc, wj = n1 - jc, wi = n1 - ic;
+  const unsigned r1 = g->r1, r2 = g->r2, total = r1 + r2 + g->r3;
+  unsigned r = (t - core) * 128u + (unsigned)wave * 32u + (unsigned)l32;
+  const bool valid = r < total;
+  if (!valid) r = total - 1u;
+  if (r < r1) {                         // whole planes k >= kc
+    const unsigned plane = n1 * n1, kk = r / plane, rem = r - kk * plane, jj = rem / n1;
+    k = (int)(kc + kk); j = (int)jj; i = (int)(rem - jj * n1);
+  } else if (r - r1 < r2) {             // k < kc, j >= jc
+    r -= r1;
+    const unsigned slab = wj * n1, kk = r / slab, rem = r - kk * slab, jj = rem / n1;
+    k = (int)kk; j = (int)(jc + jj); i = (int)(rem - jj * n1);
+  } else {                              // k < kc, j < jc, i >= ic
+    r -= r1 + r2;
+    const unsigned slab = jc * wi, kk = r / slab, rem = r - kk * slab, jj = rem / wi;
+    k = (int)kk; j = (int)jj; i = (int)(ic + rem - jj * wi);
+  }
+  return valid;
+}
+// a0: np.linspace per axis in float64, cast to float32 (reference demo/demo.py:297-305)
+__device__ __forceinline__ void grid_xyz(const Geom* g, int i, int j, int k, float& x, float& y, float& z) {
+  const int res = g->res;
+  k += g->z0;
+  x = (float)(i == res ? g->hi[0] : __dadd_rn(__dmul_rn((double)i, g->step[0]), g->lo[0]));
+  y = (float)(j == res ? g->hi[1] : __dadd_rn(__dmul_rn((double)j, g->step[1]), g->lo[1]));
+  z = (float)(k == res ? g->hi[2] : __dadd_rn(__dmul_rn((double)k, g->step[2]), g->lo[2]));
+}
 
 // ---- weight pipeline: global -> LDS ring by LDS-DMA, shared by the 4 waves ----
 // The fragment stream is consumed in stages of 16 pairs (32 KiB).  Four ring
@@ -257,7 +331,7 @@ constexpr int NSLOT = 4;                                 // ring slots
 constexpr int STAGES_PER_STREAM = PAIRS / STAGE_PAIRS;   // 66
 constexpr int STAGES_PER_TILE = 2 * STAGES_PER_STREAM;   // 132
 constexpr int SP_LDS_FLOATS = 2 * SP_SIZE;
-constexpr int LDS_BYTES = NSLOT * STAGE_BYTES + SP_LDS_FLOATS * 4;
+constexpr int LDS_BYTES = NSLOT * STAGE_BYTES + SP_LDS_FLOATS * 4 + 192;   // ring | parameters | Geom
 static_assert(PAIRS % STAGE_PAIRS == 0, "stream must be a whole number of stages");
 
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -637,8 +711,10 @@ __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float* sp_lds = (float*)(lds + NSLOT * STAGE_BYTES);
   for (int i = threadIdx.x; i < SP_LDS_FLOATS; i += 256) sp_lds[i] = a.sp[i];
+  Geom* geom = (Geom*)(lds + NSLOT * STAGE_BYTES + SP_LDS_FLOATS * 4);
+  geom_store(geom, a);
   __syncthreads();
-  const long long ntiles = (a.n + 127) / 128;
+  const long long ntiles = a.ntiles;
   Pipe pipe;
   pipe.ws = (const char*)a.ws;
   pipe.ring = lds;
@@ -674,26 +750,21 @@ __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
   }
   for (long long tile = tile_first; tile < tile_end; tile += tile_step) {
     long long p = tile * 128 + pipe.wave * 32 + (pipe.lane & 31);
-    const bool valid = p < a.n;
+    bool valid = p < a.n;
     if (!valid) p = a.n - 1;
     float x, y, z, xr, yr, zr;
     if (a.grid_mode) {
-      // a0: np.linspace per axis in float64, cast to float32 (reference demo/demo.py:297-305)
-      const int n1 = a.res + 1;
-      int i = (int)(p % n1);
-      long long q = p / n1;
-      int j = (int)(q % n1);
-      int k = (int)(q / n1) + a.z0;
-      x = (float)(i == a.res ? a.hi[0] : __dadd_rn(__dmul_rn((double)i, a.step[0]), a.lo[0]));
-      y = (float)(j == a.res ? a.hi[1] : __dadd_rn(__dmul_rn((double)j, a.step[1]), a.lo[1]));
-      z = (float)(k == a.res ? a.hi[2] : __dadd_rn(__dmul_rn((double)k, a.step[2]), a.lo[2]));
+      int i, j, k;
+      valid = grid_point(geom, (unsigned)tile, pipe.wave, pipe.lane & 31, i, j, k);
+      p = ((long long)k * geom->n1 + j) * geom->n1 + i;
+      grid_xyz(geom, i, j, k, x, y, z);
       xr = x; yr = y; zr = z;
     } else {
       x = a.pts[3 * p]; y = a.pts[3 * p + 1]; z = a.pts[3 * p + 2];
       xr = a.pts_rot[3 * p]; yr = a.pts_rot[3 * p + 1]; zr = a.pts_rot[3 * p + 2];
     }
     float u, v;
-    project(a.T, x, y, z, u, v);
+    project(geom->T, x, y, z, u, v);
     float pred = 0.0f;   // global stream first, then local: pred = g + l (reference models/model_normalization.py:204)
 #pragma unroll 1
     for (int strm = 0; strm < 2; ++strm)
@@ -730,7 +801,7 @@ constexpr int XL_SHIFT = 11;    // x - f16(x) is scaled by 2^11 before its fp8 c
 // LDS of the mixed-precision kernel: ring | small parameters [2][SP_MX_LDS] | B4 of the global stream [512] | parked operands
 constexpr int MX_SP_BYTES = (2 * SP_MX_LDS + 512) * 4;
 constexpr int MX_PARK_BYTES_PER_WAVE = 4096;   // two 8-register operands (fp8 residuals of h2 groups 2, 3) per lane
-constexpr int MX_LDS_BYTES = NSLOT * STAGE_BYTES + MX_SP_BYTES + 4 * MX_PARK_BYTES_PER_WAVE;
+constexpr int MX_LDS_BYTES = NSLOT * STAGE_BYTES + MX_SP_BYTES + 4 * MX_PARK_BYTES_PER_WAVE + 192;   // ... | Geom
 static_assert(MX_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 struct Ring8 {
@@ -982,41 +1053,75 @@ __device__ __forceinline__ int fp8s_hi(int r, float a, float b, float inv_scale)
   asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(r) : "v"(a), "v"(b), "s"(inv_scale));
   return r;
 }
-// step I (0..7) of the in-place split of an accumulator pair (see XG), ReLU included; two parts of 7 VALU ops so
-// that it can be spread over MFMA shadows
-struct CvtMx {
-  int xl8;   // the half-written fp8 residual register between the two parts
-};
+// The in-place split of an operand group (see XG), ReLU included, as a software pipeline of single VALU ops.
+// The 16 "parts" of a group (part = 2 * I + block: step I = 0..7 on the two elements a[I], a[8+I] of block a or
+// b[I], b[8+I] of block b) each go through four stages
+//     A  r0, r1 = relu of the two elements            B  f16 pair -> a[I] / b[I];  fp8(r0, r1) -> half of a[8+I]
+//     C  l0, l1 = r - f16(r)                          D  fp8(l * 2^11) -> half of b[8+I]
+// and bundle t = 0..18 runs D(t-3), C(t-2), B(t-1), A(t): the (up to) 7 ops of a bundle do not depend on each other,
+// so they issue back to back in an MFMA shadow (the same 7 ops as one dependent chain cost ~10 cycles each there).
+// Program order keeps the in-place hazards right: part 2I+1 reads b[8+I] (stage A, bundle 2I+1) before part 2I
+// writes its lower half (stage D, bundle 2I+3).
 constexpr float XL_INV_SCALE = 1.0f / (float)(1 << XL_SHIFT);
-template <int I>
-__device__ __forceinline__ void cvt_mx_a(XG& x, CvtMx& st) {   // the two elements of block a
-  const float r0 = relu1(__int_as_float(x.a[I])), r1 = relu1(__int_as_float(x.a[8 + I]));
-  const int hp = cvt_pk_f16(r0, r1);
-  const float l0 = res_lo(hp, r0), l1 = res_hi(hp, r1);
-  const int x8 = fp8_lo(r0, r1);
-  st.xl8 = fp8s_lo(l0, l1, XL_INV_SCALE);
-  x.a[I] = hp;
-  x.a[8 + I] = x8;   // upper half follows in part b
+struct CvtMx {
+  float r[2][2];   // ReLU'd elements of the parts in stages A..C (two generations)
+  float l[2];      // residuals between C and D
+};
+template <int PART, int STAGE, int J>
+__device__ __forceinline__ void mx_uop(XG& x, CvtMx& st) {
+  constexpr int I = PART >> 1, blk = PART & 1, gen = PART & 1;
+  if constexpr (STAGE == 0) {
+    if constexpr (J == 0) st.r[gen][0] = relu1(__int_as_float(blk ? x.b[I] : x.a[I]));
+    else st.r[gen][1] = relu1(__int_as_float(blk ? x.b[8 + I] : x.a[8 + I]));
+  } else if constexpr (STAGE == 1) {
+    if constexpr (J == 0) {
+      const int hp = cvt_pk_f16(st.r[gen][0], st.r[gen][1]);
+      if constexpr (blk) x.b[I] = hp; else x.a[I] = hp;
+    } else {
+      if constexpr (blk) x.a[8 + I] = fp8_hi(x.a[8 + I], st.r[gen][0], st.r[gen][1]);
+      else x.a[8 + I] = fp8_lo(st.r[gen][0], st.r[gen][1]);
+    }
+  } else if constexpr (STAGE == 2) {
+    const int hp = blk ? x.b[I] : x.a[I];
+    if constexpr (J == 0) st.l[0] = res_lo(hp, st.r[gen][0]);
+    else st.l[1] = res_hi(hp, st.r[gen][1]);
+  } else {
+    if constexpr (blk) x.b[8 + I] = fp8s_hi(x.b[8 + I], st.l[0], st.l[1], XL_INV_SCALE);
+    else x.b[8 + I] = fp8s_lo(st.l[0], st.l[1], XL_INV_SCALE);
+  }
 }
-template <int I>
-__device__ __forceinline__ void cvt_mx_b(XG& x, CvtMx& st) {   // the two elements of block b
-  const float r0 = relu1(__int_as_float(x.b[I])), r1 = relu1(__int_as_float(x.b[8 + I]));
-  const int hp = cvt_pk_f16(r0, r1);
-  const float l0 = res_lo(hp, r0), l1 = res_hi(hp, r1);
-  const int x8 = fp8_hi(x.a[8 + I], r0, r1);
-  const int xl8 = fp8s_hi(st.xl8, l0, l1, XL_INV_SCALE);
-  x.b[I] = hp;
-  x.a[8 + I] = x8;
-  x.b[8 + I] = xl8;
+struct Uop { int part, stage, j; };
+constexpr int MX_UOPS = 16 * 7;
+constexpr Uop mx_uop_at(int n) {   // the n-th op of a group's split in pipelined order
+  int c = 0;
+  for (int t = 0; t < 16 + 3; ++t)
+    for (int stage = 3; stage >= 0; --stage) {
+      const int part = t - stage;
+      if (part < 0 || part > 15) continue;
+      for (int j = 0; j < (stage == 3 ? 1 : 2); ++j, ++c)
+        if (c == n) return Uop{part, stage, j};
+    }
+  return Uop{-1, -1, -1};
 }
-__device__ __forceinline__ void cvt_mx_all(XG& x) {
-  static_for<8>([&](auto ic) {
-    constexpr int I = decltype(ic)::value;
-    CvtMx st;
-    cvt_mx_a<I>(x, st);
-    cvt_mx_b<I>(x, st);
+template <int N0, int CNT>
+__device__ __forceinline__ void mx_uops(XG& x, CvtMx& st) {   // ops N0 .. N0 + CNT - 1
+  static_for<CNT>([&](auto ic) {
+    constexpr Uop u = mx_uop_at(N0 + decltype(ic)::value);
+    static_assert(u.part >= 0, "op index out of range");
+    mx_uop<u.part, u.stage, u.j>(x, st);
   });
 }
+__device__ __forceinline__ void cvt_mx_all(XG& x) {
+  CvtMx st;
+  mx_uops<0, MX_UOPS>(x, st);
+}
+// ops of the split per MFMA shadow of a group_step (16 groups host one split: 7 ops per group)
+#ifndef MX_CVT_Q
+#define MX_CVT_Q 1, 1, 1, 1, 1, 2
+#endif
+constexpr int MX_Q[6] = {MX_CVT_Q};
+constexpr int mx_q_start(int m) { int c = 0; for (int i = 0; i < m; ++i) c += MX_Q[i]; return c; }
+static_assert(mx_q_start(6) == 7, "7 ops per group");
 
 __device__ __forceinline__ int load_scale(const float* sp, int layer) {
   int w = ((const int*)(sp + SP_SC))[layer];
@@ -1041,6 +1146,77 @@ __device__ __forceinline__ void park_store(uint4* park, int t, const XG& x) {
   park[t * 128] = lo;
   park[t * 128 + 64] = hi;
 }
+// ReLU + bf16 hi/lo split of one 32x32 accumulator block (16 elements = 8 pairs per lane) for the bf16 triple of
+// fold2/conv2, as a software pipeline like the one above.  Pair p goes through
+//     S0 read a0, a1 out of the AGPRs    S1 v = relu(a)            S2 hi = bf16 pair of v
+//     S3 t = hi expanded to f32          S4 v -= t (exact)          S5 lo = bf16 pair of v
+// and bundle t = 0..12 runs S5(t-5) .. S0(t): 9 independent instructions.  Fragments are kept as int vectors
+// (element (e & 7) >> 1 of vector e >> 3 holds the pair e, e+1).
+typedef __attribute__((ext_vector_type(2))) float floatx2;
+struct CvtBf {
+  float a[2];
+  floatx2 v[4];   // four generations
+  floatx2 t;
+};
+__device__ __forceinline__ int cvt_pk_bf16(float a, float b) {
+  int r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int PAIR, int STAGE, int J, class AccT>
+__device__ __forceinline__ void bf_uop(const AccT& acc, CvtBf& st, intx4 (&hi)[2], intx4 (&lo)[2]) {
+  constexpr int e = 2 * PAIR, g = PAIR & 3;
+  if constexpr (STAGE == 0) {
+    st.a[J] = acc[e + J];
+    asm volatile("" : "+v"(st.a[J]));   // the AGPR read happens here
+  } else if constexpr (STAGE == 1) {
+    st.v[g][J] = relu1(st.a[J]);
+  } else if constexpr (STAGE == 2) {
+    hi[e >> 3][(e & 7) >> 1] = cvt_pk_bf16(st.v[g][0], st.v[g][1]);
+  } else if constexpr (STAGE == 3) {
+    const int hp = hi[e >> 3][(e & 7) >> 1];
+    if constexpr (J == 0) st.t[0] = __int_as_float(hp << 16);
+    else st.t[1] = __int_as_float(hp & (int)0xffff0000);
+  } else if constexpr (STAGE == 4) {
+    asm("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(st.v[g]) : "v"(st.t));
+  } else {
+    lo[e >> 3][(e & 7) >> 1] = cvt_pk_bf16(st.v[g][0], st.v[g][1]);
+  }
+}
+constexpr int BF_UOPS = 8 * 9;
+constexpr int bf_stage_ops(int stage) { return (stage == 2 || stage >= 4) ? 1 : 2; }
+constexpr Uop bf_uop_at(int n) {
+  int c = 0;
+  for (int t = 0; t < 8 + 5; ++t)
+    for (int stage = 5; stage >= 0; --stage) {
+      const int pair = t - stage;
+      if (pair < 0 || pair > 7) continue;
+      for (int j = 0; j < bf_stage_ops(stage); ++j, ++c)
+        if (c == n) return Uop{pair, stage, j};
+    }
+  return Uop{-1, -1, -1};
+}
+template <int N0, int CNT, class AccT>
+__device__ __forceinline__ void bf_uops(const AccT& acc, CvtBf& st, intx4 (&hi)[2], intx4 (&lo)[2]) {
+  static_for<CNT>([&](auto ic) {
+    constexpr Uop u = bf_uop_at(N0 + decltype(ic)::value);
+    static_assert(u.part >= 0, "op index out of range");
+    bf_uop<u.part, u.stage, u.j>(acc, st, hi, lo);
+  });
+}
+// instructions of the split per MFMA shadow of a pair step: [pair parity][gap]; 9 per two pair steps
+#ifndef BF_CVT_Q
+#define BF_CVT_Q {2, 2, 1}, {2, 1, 1}
+#endif
+constexpr int BF_Q[2][3] = {BF_CVT_Q};
+constexpr int bf_q_start(int P, int gap) {   // first op of pair step P's shadow `gap`
+  int c = 0;
+  for (int p = 0; p < P; ++p) c += BF_Q[p & 1][0] + BF_Q[p & 1][1] + BF_Q[p & 1][2];
+  for (int i = 0; i < gap; ++i) c += BF_Q[P & 1][i];
+  return c;
+}
+static_assert(bf_q_start(16, 0) == BF_UOPS, "72 instructions per block");
+
 template <class Tail>
 __device__ __forceinline__ void l3_stage_mx(Pipe& pipe, Ring8& rg, intx16& acc3, const XG (&h2)[4], const uint4* park,
                                             const Scales& sc, Tail tail) {
@@ -1082,19 +1258,20 @@ __device__ __forceinline__ float stream_pass_mx(const bool LOCAL, Pipe& pipe, Ri
     gather(t[0], 0);
     static_for<16>([&](auto nc) {
       constexpr int nb4 = decltype(nc)::value;
+      constexpr int tb = nb4 & 1;
       if constexpr (nb4 + 1 < 16) gather(t[(nb4 + 1) & 1], nb4 + 1);
       // the blend of the four corners (fold2/conv1's bias was added to the map by disn_sdf_set_image)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc4[nb4][4 * q + e] = cn.w[0] * t[nb4 & 1][q][e];
+        for (int e = 0; e < 4; ++e) acc4[nb4][4 * q + e] = cn.w[0] * t[tb][q][e];
 #pragma unroll
       for (int c = 1; c < 4; ++c)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            acc4[nb4][4 * q + e] = fmaf(cn.w[c], t[nb4 & 1][4 * c + q][e], acc4[nb4][4 * q + e]);
+            acc4[nb4][4 * q + e] = fmaf(cn.w[c], t[tb][4 * c + q][e], acc4[nb4][4 * q + e]);
       asm volatile("" : "+a"(acc4[nb4]));
     });
   } else {
@@ -1155,55 +1332,74 @@ __device__ __forceinline__ float stream_pass_mx(const bool LOCAL, Pipe& pipe, Ri
   cvt_mx_all(xc);
   asm volatile("s_nop 7" ::: "memory");
   // Two operand sets in ping-pong.  The chain is a loop of three double steps (m = 0..5) plus a tail (m = 6, 7)
-  // so that the hot code stays small: straight-line code that misses the instruction cache ran 25-40 % slower
-  // per stage than the same stages inside a loop.
+  // so that the hot code stays small.  Step m: blocks 2m+2, 2m+3 of h3 are accumulated into nx (2 stages), then cu
+  // feeds the sixteen fold2/conv1 accumulators (4 stages) while nx is split in the MFMA shadows.  The bias of a
+  // block is read into its accumulator ahead of the stage that needs it: nx.b's in the last long shadow of nx.a's stage,
+  // and the one of the NEXT step's first block into cu.a in the last two shadows of this step, where cu.a is dead
+  // (k-steps 0, 1 were read by MFMAs 0, 1; the fp8 operand a[8..15] by MFMA 4, which has finished when MFMA 5,
+  // chained on the same accumulator, has issued).
   XG xd;
-  auto chain = [&](XG& cu, XG& nx, const int m, auto with_next) {
-    constexpr bool NEXT = decltype(with_next)::value;
+  xd.a = as_bits(bias_init(sp + SP_B3, 64, h));
+  // lane >> 5, recomputed from the DMA offset register where it is needed inside the chain (one live register less)
+  auto half_of = [&]() {
+    unsigned vo = pipe.voff;
+    asm volatile("" : "+v"(vo));
+    return (int)(vo >> 7);
+  };
+  auto chain = [&](XG& cu, XG& nx, const int m, auto with_next, auto with_pre) {
+    constexpr bool NEXT = decltype(with_next)::value, PRE = decltype(with_pre)::value;
     if constexpr (NEXT) {
-      nx.a = as_bits(bias_init(sp + SP_B3, 64 * m + 64, h));
-      l3_stage_mx(pipe, rg, nx.a, h2, park, sc3, [] {});
-      nx.b = as_bits(bias_init(sp + SP_B3, 64 * m + 96, h));
+      l3_stage_mx(pipe, rg, nx.a, h2, park, sc3, [&] { nx.b = as_bits(bias_init(sp + SP_B3, 64 * m + 96, half_of())); });
       l3_stage_mx(pipe, rg, nx.b, h2, park, sc3, [] {});
     }
     CvtMx cs;
+    const float* bnext = sp + SP_B3 + 64 * m + 128;
     static_for<4>([&](auto sc_) {
       constexpr int S = decltype(sc_)::value;
       static_for<4>([&](auto gc) {
         constexpr int G = decltype(gc)::value;
-        constexpr int T = 4 * S + G;          // group T of the phase: half a split step (T >> 1) in its last long shadow
+        constexpr int T = 4 * S + G;          // group T of the phase hosts ops 7T .. 7T+6 of nx's split
         group_step<G, true>(pipe, rg, acc4[T], cu, sc4, [&](auto mm) {
           constexpr int M = decltype(mm)::value;
-          if constexpr (NEXT && M == 5 && (T & 1) == 0) cvt_mx_a<(T >> 1)>(nx, cs);
-          if constexpr (NEXT && M == 5 && (T & 1) == 1) cvt_mx_b<(T >> 1)>(nx, cs);
+          if constexpr (NEXT) mx_uops<7 * T + mx_q_start(M), MX_Q[M]>(nx, cs);
+          if constexpr (PRE && T == 15 && (M == 4 || M == 5)) {
+            const int h4 = 4 * half_of();
+#pragma unroll
+            for (int q = 2 * (M - 4); q < 2 * (M - 4) + 2; ++q) {
+              const floatx4 v = *(const floatx4*)(bnext + 8 * q + h4);
+              cu.a[4 * q + 0] = __float_as_int(v[0]); cu.a[4 * q + 1] = __float_as_int(v[1]);
+              cu.a[4 * q + 2] = __float_as_int(v[2]); cu.a[4 * q + 3] = __float_as_int(v[3]);
+            }
+          }
         });
       });
     });
   };
 #pragma unroll 1
   for (int mm = 0; mm < 3; ++mm) {
-    chain(xc, xd, 2 * mm, std::true_type{});
-    chain(xd, xc, 2 * mm + 1, std::true_type{});
+    chain(xc, xd, 2 * mm, std::true_type{}, std::true_type{});
+    chain(xd, xc, 2 * mm + 1, std::true_type{}, std::true_type{});
   }
-  chain(xc, xd, 6, std::true_type{});
-  chain(xd, xc, 7, std::false_type{});
+  chain(xc, xd, 6, std::true_type{}, std::false_type{});
+  chain(xd, xc, 7, std::false_type{}, std::false_type{});
   // fold2/conv2 (512 -> 256) on the bf16 triple, consuming the fold2/conv1 accumulators block by block (unrolled:
   // the accumulator file cannot be indexed by a loop counter)
   floatx16 acc5[8];
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) acc5[nb] = bias_init(sp + SP_B5, 32 * nb, h);
-  bf16x8 yhi[2][2], ylo[2][2];
-  CvtState cs5;
+  intx4 yhi[2][2], ylo[2][2];
+  CvtBf cs5;
   drain_a(acc4[0]);
-#pragma unroll
-  for (int e = 0; e < 16; e += 2) cvt_pair(acc4[0], e, yhi[0], ylo[0]);
+  bf_uops<0, BF_UOPS>(acc4[0], cs5, yhi[0], ylo[0]);
   static_for<16>([&](auto nc) {
     constexpr int nb4 = decltype(nc)::value;
     constexpr int cur = nb4 & 1, nx = cur ^ 1, nn = nb4 < 15 ? nb4 + 1 : 15;
     static_for<16>([&](auto pc) {
       constexpr int P = decltype(pc)::value;
-      pair_step8<P, false>(pipe, rg, acc5[P >> 1], yhi[cur][P & 1], ylo[cur][P & 1], [&](auto mm) {
-        if constexpr (nb4 < 15 && decltype(mm)::value == 2) cvt_part<P>(acc4[nn], cs5, yhi[nx], ylo[nx]);
+      pair_step8<P, false>(pipe, rg, acc5[P >> 1], __builtin_bit_cast(bf16x8, yhi[cur][P & 1]),
+                           __builtin_bit_cast(bf16x8, ylo[cur][P & 1]), [&](auto mm) {
+        constexpr int M = decltype(mm)::value;
+        if constexpr (nb4 < 15) bf_uops<bf_q_start(P, M), BF_Q[P & 1][M]>(acc4[nn], cs5, yhi[nx], ylo[nx]);
       });
     });
   });
@@ -1229,9 +1425,11 @@ __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
   for (int i = threadIdx.x; i < 2 * SP_MX_LDS; i += 256)
     sp_lds[i] = a.sp[(i < SP_MX_LDS ? 0 : SP_SIZE - SP_MX_LDS) + i];   // both streams' blocks without their B4 tails
   for (int i = threadIdx.x; i < 512; i += 256) sp_lds[2 * SP_MX_LDS + i] = a.sp[SP_B4 + i];   // global stream's B4 (+ hoisted term)
+  Geom* geom = (Geom*)(lds + NSLOT * STAGE_BYTES + MX_SP_BYTES + 4 * MX_PARK_BYTES_PER_WAVE);
+  geom_store(geom, a);
   __syncthreads();
   uint4* park = (uint4*)(lds + NSLOT * STAGE_BYTES + MX_SP_BYTES + (threadIdx.x >> 6) * MX_PARK_BYTES_PER_WAVE) + (threadIdx.x & 63);
-  const long long ntiles = (a.n + 127) / 128;
+  const long long ntiles = a.ntiles;
   Pipe pipe;
   pipe.ws = (const char*)a.ws;
   pipe.ring = lds;
@@ -1266,32 +1464,31 @@ __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
 #pragma unroll 1
     for (int strm = 0; strm < 2; ++strm) {
       // the point is recomputed for each stream instead of being carried through the first one in registers
-      long long p = tile * 128 + pipe.wave * 32 + (pipe.lane & 31);
-      if (p >= a.n) p = a.n - 1;
       float x, y, z, xr, yr, zr;
       if (a.grid_mode) {
-        // p -> (i, j, k) without 64-bit integer division: the plane index by an (exact) double division,
-        // the rest in 32 bits (a plane has at most 2048^2 points)
-        const unsigned n1 = (unsigned)a.res + 1u, plane = n1 * n1;
-        const unsigned kz = (unsigned)((double)p / (double)plane);
-        const unsigned rem = (unsigned)(p - (long long)kz * plane);
-        const unsigned j = rem / n1, i = rem - j * n1;
-        const int k = (int)kz + a.z0;
-        x = (float)((int)i == a.res ? a.hi[0] : __dadd_rn(__dmul_rn((double)i, a.step[0]), a.lo[0]));
-        y = (float)((int)j == a.res ? a.hi[1] : __dadd_rn(__dmul_rn((double)j, a.step[1]), a.lo[1]));
-        z = (float)(k == a.res ? a.hi[2] : __dadd_rn(__dmul_rn((double)k, a.step[2]), a.lo[2]));
+        int i, j, k;
+        grid_point(geom, (unsigned)tile, pipe.wave, pipe.lane & 31, i, j, k);
+        grid_xyz(geom, i, j, k, x, y, z);
         xr = x; yr = y; zr = z;
       } else {
+        long long p = tile * 128 + pipe.wave * 32 + (pipe.lane & 31);
+        if (p >= a.n) p = a.n - 1;
         x = a.pts[3 * p]; y = a.pts[3 * p + 1]; z = a.pts[3 * p + 2];
         xr = a.pts_rot[3 * p]; yr = a.pts_rot[3 * p + 1]; zr = a.pts_rot[3 * p + 2];
       }
       float u, v;
-      project(a.T, x, y, z, u, v);
+      project(geom->T, x, y, z, u, v);
       pred = __fadd_rn(pred, stream_pass_mx(strm != 0, pipe, rg, sp_lds + strm * SP_MX_LDS, sp_lds + 2 * SP_MX_LDS, park,
                                                a.pmap, xr, yr, zr, u, v));
     }
-    const long long p = tile * 128 + pipe.wave * 32 + (pipe.lane & 31);
-    if (p < a.n && pipe.lane < 32) a.out[p] = a.scale_out ? (float)((double)pred / 10.0) : pred;
+    long long p = tile * 128 + pipe.wave * 32 + (pipe.lane & 31);
+    bool valid = p < a.n;
+    if (a.grid_mode) {
+      int i, j, k;
+      valid = grid_point(geom, (unsigned)tile, pipe.wave, pipe.lane & 31, i, j, k);
+      p = ((long long)k * geom->n1 + j) * geom->n1 + i;
+    }
+    if (valid && pipe.lane < 32) a.out[p] = a.scale_out ? (float)((double)pred / 10.0) : pred;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1581,7 +1778,8 @@ static int launch_decode(DisnCtx* ctx, DecodeArgs& a, const float* trans_mat, hi
   a.sp = (const float*)s->sp.p;
   a.pmap = (const float*)s->pmap.p;
   if (a.n <= 0) return DISN_OK;
-  const long long tiles = (a.n + 127) / 128;
+  if (!a.grid_mode) a.ntiles = (a.n + 127) / 128;
+  const long long tiles = a.ntiles;
   if (tiles * STAGES_PER_TILE > 0x7fffffffll) return disn_fail(ctx, DISN_E_ARG, "too many points for one launch");
   const unsigned blocks = (unsigned)(tiles < s->num_cu ? tiles : s->num_cu);
   if (s->decoder == DISN_DECODER_MIXED) {
@@ -1620,6 +1818,20 @@ extern "C" int disn_sdf_grid(DisnCtx* ctx, const float* trans_mat, const double*
     a.step[q] = (sdf_params[3 + q] - sdf_params[q]) / (double)res;  // np.linspace: delta / div
   }
   a.n = (long long)(z1 - z0 + 1) * (res + 1) * (res + 1);
+  // tiles: bricks of 8 x 4 x 4 points over the core of the slab, the rest linearly (grid_point)
+  a.n1 = res + 1;
+  a.nk = z1 - z0 + 1;
+  a.ic = a.n1 & ~7; a.jc = a.n1 & ~3; a.kc = a.nk & ~3;
+  const int nbi = a.ic / 8, nbj = a.jc / 4, nbk = a.kc / 4;
+  auto pow2_div = [](int n, int cap) { int sh = 0; while (sh < cap && n > 0 && n % (2 << sh) == 0) ++sh; return sh; };
+  a.sbi = pow2_div(nbi, 2); a.sbj = pow2_div(nbj, 3); a.sbk = pow2_div(nbk, 3);   // super-brick <= 32^3 points
+  a.nsi = nbi >> a.sbi; a.nsj = nbj >> a.sbj;
+  a.core_tiles = (long long)nbi * nbj * nbk;
+  const long long r1 = (long long)(a.nk - a.kc) * a.n1 * a.n1, r2 = (long long)a.kc * (a.n1 - a.jc) * a.n1;
+  const long long r3 = (long long)a.kc * a.jc * (a.n1 - a.ic);
+  if (a.core_tiles == 0) { a.nsi = a.nsj = 1; }
+  a.r1 = (unsigned)r1; a.r2 = (unsigned)r2; a.r3 = (unsigned)r3;
+  a.ntiles = a.core_tiles + (r1 + r2 + r3 + 127) / 128;
   a.scale_out = 1;
   a.out = sdf_out;
   return launch_decode(ctx, a, trans_mat, (hipStream_t)stream);

@@ -127,3 +127,82 @@ def test_state_errors(ctx):
     with pytest.raises(DisnError):
         c.mc_emit()
     c.close()
+
+
+@pytest.mark.parametrize("decoder", ["mixed", "bf16x3"])
+@pytest.mark.parametrize("res,z0,z1", [(3, 0, 3), (7, 0, 7), (8, 0, 8), (12, 1, 11), (20, 0, 3), (33, 5, 5),
+                                        (40, 0, 40), (64, 0, 64), (64, 7, 38)])
+def test_grid_tiling_matches_points_mode(ctx, model, decoder, res, z0, z1):
+    """The grid is walked in bricks of 8 x 4 x 4 points (super-bricks for L2 locality) plus three linear remainder
+    boxes: every (res, slab) shape -- core only, remainders only, both -- must give, bit for bit, what the same
+    points give through disn_sdf_points (one point's result does not depend on its tile)."""
+    maps, gf, w = model
+    ctx.set_decoder(decoder)
+    try:
+        ctx.set_weights(w)
+        ctx.set_image(maps, gf)
+        got = ctx.sdf_grid(net.GT_TRANS_MAT, res, z0=z0, z1=z1)
+        l = np.linspace(-1, 1, res + 1)
+        z, y, x = np.meshgrid(l[z0:z1 + 1], l, l, indexing="ij")
+        pts = np.stack([x, y, z], -1).astype(np.float32).reshape(-1, 3)
+        raw = ctx.sdf_points(net.GT_TRANS_MAT, pts)
+        want = (raw.double() / 10.0).float().reshape(z1 - z0 + 1, res + 1, res + 1)
+        assert torch.equal(got, want)
+    finally:
+        ctx.set_decoder("mixed")
+
+
+def test_decoders_agree_and_meet_tolerance(ctx, model):
+    """Both decoder arithmetics (disn_sdf_set_decoder) against the float64 oracle on the same points."""
+    maps, gf, w = model
+    rng = np.random.default_rng(21)
+    pts = rng.uniform(-1, 1, (4096, 3)).astype(np.float32)
+    want64 = net.sdf_points(pts, pts, net.GT_TRANS_MAT, maps, gf, w, dtype=torch.float64)
+    try:
+        for name in ("mixed", "bf16x3"):
+            ctx.set_decoder(name)
+            ctx.set_weights(w)
+            ctx.set_image(maps, gf)
+            got = ctx.sdf_points(net.GT_TRANS_MAT, pts).cpu().numpy()
+            err = np.abs(got - want64).max() / 10.0
+            print("%s: max err after /10 %.2e" % (name, err))
+            assert err <= TOL_SDF
+        with pytest.raises(Exception):
+            ctx.set_decoder("fp4")
+    finally:
+        ctx.set_decoder("mixed")
+
+
+def test_mixed_decoder_adversarial_weight_scales(ctx):
+    """The mixed decoder's fp8 residual terms carry per-layer power-of-two scales: weights whose rows differ by
+    large factors, large biases and a raw output of ~10 units (profiles/precision_budget.json's hardest sets)
+    must stay inside the tolerance, and activations beyond fp8's range must not produce NaN/inf."""
+    maps, gf = net.synthetic_features(seed=6)
+    w = net.xavier_decoder_weights(seed=6, bias_scale=0.3)
+    rng = np.random.default_rng(6)
+    for k in list(w):
+        if k.endswith(("f1c3_w", "f2c1_w")):
+            w[k] = (w[k] * np.exp(rng.normal(0, 0.7, (1, w[k].shape[1]))).astype(np.float32)).astype(np.float32)
+    pts = rng.uniform(-1, 1, (2048, 3)).astype(np.float32)
+    raw64 = net.sdf_points(pts, pts, net.GT_TRANS_MAT, maps, gf, w, dtype=torch.float64)
+    scale = np.float32(10.0 / np.abs(raw64).max())
+    for k in list(w):
+        if k.endswith("f2c5_w"):
+            w[k] = w[k] * scale
+    want64 = net.sdf_points(pts, pts, net.GT_TRANS_MAT, maps, gf, w, dtype=torch.float64)
+    ctx.set_decoder("mixed")
+    ctx.set_weights(w)
+    ctx.set_image(maps, gf)
+    got = ctx.sdf_points(net.GT_TRANS_MAT, pts).cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - want64).max() / 10.0
+    print("|raw| up to %.1f, max err after /10 %.2e" % (np.abs(want64).max(), err))
+    assert err <= TOL_SDF
+    # huge first-layer weights push activations far beyond fp8's 448: results stay finite (saturating conversions)
+    w2 = dict(w)
+    for k in list(w2):
+        if k.endswith("f1c1_w"):
+            w2[k] = w2[k] * np.float32(3000.0)
+    ctx.set_weights(w2)
+    ctx.set_image(maps, gf)
+    assert np.isfinite(ctx.sdf_points(net.GT_TRANS_MAT, pts).cpu().numpy()).all()

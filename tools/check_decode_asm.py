@@ -29,7 +29,7 @@ def check(asm, name):
     first, last = mf[0], mf[-1]
     bad = []
     for i, l in enumerate(code):
-        if re.search(r"\bm0\b", l) and not re.fullmatch(r"s_mov_b32 m0, s\d+", l):
+        if re.search(r"\bm0\b", l) and not re.fullmatch(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi|ttmp\d+)", l):
             bad.append((i, "M0 used by the compiler: " + l))
         if first < i < last:
             if l.startswith(("scratch_", "buffer_", "global_store", "flat_")) or \

@@ -22,9 +22,24 @@ def variant(name, s):
     elif name == "nosync":    # no rendezvous in the middle of a stage
         rep("    __builtin_amdgcn_s_barrier();\n    long long tw2_", "    long long tw2_")
     elif name == "nocvt":     # operand conversions in the shadows dropped
-        rep("          if constexpr (NEXT && M == 5 && (T & 1) == 0) cvt_mx_a<(T >> 1)>(nx, cs);\n", "")
-        rep("          if constexpr (NEXT && M == 5 && (T & 1) == 1) cvt_mx_b<(T >> 1)>(nx, cs);\n", "")
-        rep("        if constexpr (nb4 < 15 && decltype(mm)::value == 2) cvt_part<P>(acc4[nn], cs5, yhi[nx], ylo[nx]);\n", "")
+        rep("          if constexpr (NEXT) mx_uops<7 * T + mx_q_start(M), MX_Q[M]>(nx, cs);\n", "")
+        rep("        if constexpr (nb4 < 15) bf_uops<bf_q_start(P, M), BF_Q[P & 1][M]>(acc4[nn], cs5, yhi[nx], ylo[nx]);\n", "")
+    elif name == "g_same":    # every lane gathers pixel row 0 (no misses, one line per instruction)
+        i0 = s.find("float stream_pass_mx(")
+        s = s[:i0] + s[i0:].replace("(size_t)cn.pix[c] * 512", "(size_t)0 * 512", 1)
+    elif name == "g_hot":     # 32 distinct rows per instruction, always the same 32 (cache-resident)
+        i0 = s.find("float stream_pass_mx(")
+        s = s[:i0] + s[i0:].replace("(size_t)cn.pix[c] * 512", "(size_t)(lane & 31) * 512", 1)
+    elif name.startswith("g_expr_"):   # gather row = expression of cn.pix[c] / lane, e.g. g_expr_mod64
+        expr = {"mod64": "(size_t)(cn.pix[c] & 63) * 512", "mod4096": "(size_t)(cn.pix[c] & 4095) * 512",
+                "rows8": "(size_t)((lane & 31) >> 2) * 512", "stride137": "(size_t)((lane & 31) * 137) * 512"}[name[7:]]
+        i0 = s.find("float stream_pass_mx(")
+        s = s[:i0] + s[i0:].replace("(size_t)cn.pix[c] * 512", expr, 1)
+    elif name.startswith("mxq_"):   # another distribution of the split's ops over a group's six shadows
+        rep("#define MX_CVT_Q 0, 0, 0, 0, 3, 4", "#define MX_CVT_Q " + ", ".join(name[4:]))
+    elif name.startswith("bfq_"):   # ... of the bf16 split over a pair step's three shadows (even, odd pair)
+        d = name[4:]
+        rep("#define BF_CVT_Q {1, 2, 2}, {1, 1, 2}", "#define BF_CVT_Q {%s, %s, %s}, {%s, %s, %s}" % tuple(d))
     else:
         raise SystemExit("unknown variant " + name)
     return s

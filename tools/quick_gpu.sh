@@ -8,7 +8,7 @@ import json
 for l in open('gpurun_out/bench1.log'):
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']
-        print('ms_per_step %.2f decode_ms %.2f executed_TF %.0f issue_frac %.3f value %.3e' % (d['ms_per_step'], r['kernel_ms'], r['executed_mfma_tflops'], r['mfma_issue_frac'], d['value']))
+        print('ms_per_step %.2f decode_ms %.2f executed_TF %.0f issue_frac %.3f value %.3e' % (d['ms_per_step'], r['kernel_ms'], r['executed_mfma_tflops_bf16_rate'], r['mfma_issue_frac'], d['value']))
         break
 else:
     print(open('gpurun_out/bench1.log').read()[-1500:])

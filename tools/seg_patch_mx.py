@@ -12,7 +12,7 @@ head, s = s[:i0], s[i0:]
 rep("  // fold1/conv2 (64 -> 256): 2 stages of 4 blocks (one group each); h2 stays resident as 4 operand groups", "  if (LOCAL) TICK(0) else TICK(4)\n  // fold1/conv2 (64 -> 256): 2 stages")
 rep("  // fold1/conv3 (256 -> 512) chained into fold2/conv1 in groups of 64 features", "  TICK(1)\n  // fold1/conv3 (256 -> 512) chained")
 rep("  // Two operand sets in ping-pong.", "  TICK(2)\n  // Two operand sets in ping-pong.")
-rep("    CvtMx cs;\n    static_for<4>([&](auto sc_) {", "    TICK(3)\n    CvtMx cs;\n    static_for<4>([&](auto sc_) {")
+rep("    CvtMx cs;\n    const float* bnext", "    TICK(3)\n    CvtMx cs;\n    const float* bnext")
 rep("  // fold2/conv2 (512 -> 256) on the bf16 triple", "  TICK(5)\n  // fold2/conv2 (512 -> 256) on the bf16 triple")
 rep("  float part = 0.0f;\n", "  TICK(6)\n  float part = 0.0f;\n")
 rep("  part += __shfl_xor(part, 32, 64);\n", "  part += __shfl_xor(part, 32, 64);\n  TICK(7)\n")
