@@ -345,7 +345,9 @@ struct Frags {
 };
 
 struct Pipe {
-  const char* ws;        // global fragment stream (STAGES_PER_TILE stages, then it repeats)
+  const char* ws;        // global fragment stream: stages [ws, ws_end), then it repeats
+  const char* ws_end;
+  const char* src_next;  // stage that the next dma_setup issues (stages are set up in order)
   char* ring;            // LDS ring base
   unsigned ring32;       // its LDS byte address
   int g;                 // stage being consumed (counts across tiles)
@@ -364,7 +366,9 @@ struct Pipe {
   // instructions do not read it; `make check-m0` verifies it on the generated code), so it is
   // written only here, twice per stage, far ahead of the instructions that read it.
   __device__ __forceinline__ void dma_setup(int stage) {
-    dma_src = ws + (size_t)(stage % STAGES_PER_TILE) * STAGE_BYTES + wave * (STAGE_BYTES / 4);
+    dma_src = src_next + wave * (STAGE_BYTES / 4);
+    src_next += STAGE_BYTES;
+    if (src_next == ws_end) src_next = ws;
     dma_src_hi = dma_src + 4096;
     unsigned dst = ring32 + (stage & (NSLOT - 1)) * STAGE_BYTES + wave * (STAGE_BYTES / 4);
     dma_dst_hi = dst + 4096;
@@ -717,6 +721,8 @@ __global__ __launch_bounds__(256, 1) void sdf_decode(DecodeArgs a) {
   const long long ntiles = a.ntiles;
   Pipe pipe;
   pipe.ws = (const char*)a.ws;
+  pipe.ws_end = pipe.ws + (size_t)STAGES_PER_TILE * STAGE_BYTES;
+  pipe.src_next = pipe.ws;
   pipe.ring = lds;
   pipe.ring32 = (unsigned)(size_t)(lds_ptr_t)lds;
   pipe.g = 0;
@@ -1233,19 +1239,27 @@ __device__ __forceinline__ void l3_stage_mx(Pipe& pipe, Ring8& rg, intx16& acc3,
   });
 }
 
-__device__ __forceinline__ float stream_pass_mx(const bool LOCAL, Pipe& pipe, Ring8& rg, const float* sp,
+template <bool LOCAL>
+__device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const float* sp,
                                                 const float* b4 /*LDS: global stream's fold2/conv1 bias*/, uint4* park,
                                                 const float* __restrict__ pmap, float px, float py, float pz, float u,
                                                 float v) {
-  const int lane = pipe.lane, h = lane >> 5;
+  // h = lane >> 5 is recomputed from the DMA offset register at every use: addresses derived from a long-lived h
+  // cost registers that this kernel does not have
+  auto half_of = [&]() {
+    unsigned vo = pipe.voff;
+    asm volatile("" : "+v"(vo));
+    return (int)(vo >> 7);
+  };
+#define h half_of()
   // fold2/conv1 accumulators: bias (+ image term), exactly as in the bf16 kernel
   floatx16 acc4[16];
   Corners cn;
-  if (LOCAL) {
+  if constexpr (LOCAL) {
     asm volatile("" : "+v"(u), "+v"(v));
     cn = corners(u, v);
   }
-  if (LOCAL) {
+  if constexpr (LOCAL) {
     floatx4 t[2][16];
     auto gather = [&](floatx4 (&dst)[16], int nb4) {
 #pragma unroll
@@ -1340,12 +1354,6 @@ __device__ __forceinline__ float stream_pass_mx(const bool LOCAL, Pipe& pipe, Ri
   // chained on the same accumulator, has issued).
   XG xd;
   xd.a = as_bits(bias_init(sp + SP_B3, 64, h));
-  // lane >> 5, recomputed from the DMA offset register where it is needed inside the chain (one live register less)
-  auto half_of = [&]() {
-    unsigned vo = pipe.voff;
-    asm volatile("" : "+v"(vo));
-    return (int)(vo >> 7);
-  };
   auto chain = [&](XG& cu, XG& nx, const int m, auto with_next, auto with_pre) {
     constexpr bool NEXT = decltype(with_next)::value, PRE = decltype(with_pre)::value;
     if constexpr (NEXT) {
@@ -1416,8 +1424,14 @@ __device__ __forceinline__ float stream_pass_mx(const bool LOCAL, Pipe& pipe, Ri
   }
   part += __shfl_xor(part, 32, 64);
   return part + sp[SP_B6];
+#undef h
 }
 
+// One launch per stream: LOCAL = false evaluates the global stream and stores its raw value g, LOCAL = true the local
+// stream and stores g + l (reference models/model_normalization.py:204), scaled if asked.  Each launch walks one
+// stream's 2.1 MiB of fragments, which stay in an XCD's 4 MiB L2; both streams in one launch (4.2 MiB, cyclic) missed
+// on every line and drew the whole stream from the Infinity Cache for each round of tiles.
+template <bool LOCAL>
 __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");   // FP16_OVFL: saturating f16 / fp8 conversions
@@ -1431,7 +1445,9 @@ __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
   uint4* park = (uint4*)(lds + NSLOT * STAGE_BYTES + MX_SP_BYTES + (threadIdx.x >> 6) * MX_PARK_BYTES_PER_WAVE) + (threadIdx.x & 63);
   const long long ntiles = a.ntiles;
   Pipe pipe;
-  pipe.ws = (const char*)a.ws;
+  pipe.ws = (const char*)a.ws + (LOCAL ? (size_t)STAGES_PER_STREAM * STAGE_BYTES : 0);   // [global stream][local stream]
+  pipe.ws_end = pipe.ws + (size_t)STAGES_PER_STREAM * STAGE_BYTES;
+  pipe.src_next = pipe.ws;
   pipe.ring = lds;
   pipe.ring32 = (unsigned)(size_t)(lds_ptr_t)lds;
   pipe.g = 0;
@@ -1460,10 +1476,8 @@ __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
     tile_step = gridDim.x >> 3;
   }
   for (long long tile = tile_first; tile < tile_end; tile += tile_step) {
-    float pred = 0.0f;   // global stream first, then local: pred = g + l (reference models/model_normalization.py:204)
-#pragma unroll 1
-    for (int strm = 0; strm < 2; ++strm) {
-      // the point is recomputed for each stream instead of being carried through the first one in registers
+    float pred;
+    {
       float x, y, z, xr, yr, zr;
       if (a.grid_mode) {
         int i, j, k;
@@ -1478,8 +1492,8 @@ __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
       }
       float u, v;
       project(geom->T, x, y, z, u, v);
-      pred = __fadd_rn(pred, stream_pass_mx(strm != 0, pipe, rg, sp_lds + strm * SP_MX_LDS, sp_lds + 2 * SP_MX_LDS, park,
-                                               a.pmap, xr, yr, zr, u, v));
+      pred = stream_pass_mx<LOCAL>(pipe, rg, sp_lds + (LOCAL ? SP_MX_LDS : 0), sp_lds + 2 * SP_MX_LDS, park, a.pmap,
+                                   xr, yr, zr, u, v);
     }
     long long p = tile * 128 + pipe.wave * 32 + (pipe.lane & 31);
     bool valid = p < a.n;
@@ -1488,7 +1502,14 @@ __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
       valid = grid_point(geom, (unsigned)tile, pipe.wave, pipe.lane & 31, i, j, k);
       p = ((long long)k * geom->n1 + j) * geom->n1 + i;
     }
-    if (valid && pipe.lane < 32) a.out[p] = a.scale_out ? (float)((double)pred / 10.0) : pred;
+    if (valid && pipe.lane < 32) {
+      if constexpr (LOCAL) {
+        pred = __fadd_rn(a.out[p], pred);   // g + l
+        a.out[p] = a.scale_out ? (float)((double)pred / 10.0) : pred;
+      } else {
+        a.out[p] = pred;
+      }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1784,11 +1805,13 @@ static int launch_decode(DisnCtx* ctx, DecodeArgs& a, const float* trans_mat, hi
   const unsigned blocks = (unsigned)(tiles < s->num_cu ? tiles : s->num_cu);
   if (s->decoder == DISN_DECODER_MIXED) {
     if (!s->lds_attr_set_mx) {
-      DISN_HIP(ctx, hipFuncSetAttribute((const void*)sdf_decode_mx, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));
+      DISN_HIP(ctx, hipFuncSetAttribute((const void*)sdf_decode_mx<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));
+      DISN_HIP(ctx, hipFuncSetAttribute((const void*)sdf_decode_mx<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));
       s->lds_attr_set_mx = true;
     }
     a.ws = (const uint4*)s->wsmx.p;
-    sdf_decode_mx<<<blocks, 256, MX_LDS_BYTES, stream>>>(a);
+    sdf_decode_mx<false><<<blocks, 256, MX_LDS_BYTES, stream>>>(a);   // out = g
+    sdf_decode_mx<true><<<blocks, 256, MX_LDS_BYTES, stream>>>(a);    // out = g + l (scaled)
     DISN_HIP(ctx, hipGetLastError());
     return DISN_OK;
   }

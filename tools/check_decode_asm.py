@@ -12,16 +12,23 @@ import re
 import sys
 
 
-def kernel_text(asm, name):
-    m = re.search(r"^(_ZN\S*%s\S*):" % name, asm, re.M)
-    if not m:
+def kernel_texts(asm, name):
+    """every kernel whose mangled name contains `name` (template instances included)"""
+    found = []
+    for m in re.finditer(r"^(_ZN\S*%s\S*):" % name, asm, re.M):
+        end = asm.find("s_endpgm", m.end())
+        found.append((m.group(1), asm[m.end():end].split("\n")))
+    if not found:
         sys.exit("check_decode_asm: kernel %s not found" % name)
-    end = asm.find("s_endpgm", m.end())
-    return asm[m.end():end].split("\n")
+    return found
 
 
 def check(asm, name):
-    lines = kernel_text(asm, name)
+    for full, lines in kernel_texts(asm, name):
+        check_one(full, lines)
+
+
+def check_one(name, lines):
     code = [l.split(";")[0].strip() for l in lines]
     mf = [i for i, l in enumerate(code) if l.startswith("v_mfma")]
     if not mf:
