@@ -181,3 +181,35 @@ def coarse_median_iso(ctx, trans_mat, sdf_params=(-1, -1, -1, 1, 1, 1), res=32):
     launch): the iso used with random-init weights, which have no zero level set.  It needs the image
     to be set (ctx.set_image) and is the same number on every rank, whatever slab the rank owns."""
     return median_iso(ctx.sdf_grid(trans_mat, res, sdf_params=sdf_params))
+
+
+def mesh_by_slabs(ctx, trans_mat, res, iso, nslabs, sdf_params=(-1, -1, -1, 1, 1, 1)):
+    """The N-rank z-slab algorithm of MeshPipeline.run executed slab after slab on ONE GPU (image already set with
+    ctx.set_image): every slab evaluates its own planes plus its halo, counts, and -- once all counts are known --
+    emits with its global vertex bases; the pieces are placed and the triangles sorted once, exactly as rank 0
+    does.  Use: grids too large to mesh in one piece next to other work, and the single-GPU check that the
+    sharding reproduces the one-pass mesh.  Returns (verts f64 [V,3], tris i32 [T,3]) on the device."""
+    nz = res + 1
+    ranges = slab_ranges(nz, nslabs)
+    grids, counts = [], []
+    for lo, hi, own0, own1 in ranges:
+        sdf = ctx.sdf_grid(trans_mat, res, z0=lo, z1=hi - 1, sdf_params=sdf_params)
+        grids.append(sdf)
+        counts.append(tuple(ctx.mc_count(sdf, iso, z_offset=lo, nz_global=nz, own=(own0, own1))))
+    bases = slab_bases(counts)
+    c_total = sum(c[0] for c in counts)
+    v_total = c_total + sum(c[1] for c in counts)
+    t_total = sum(c[2] for c in counts)
+    gv = torch.empty((v_total, 3), dtype=torch.float64, device=ctx.device)
+    gt = torch.empty((t_total, 3), dtype=torch.int32, device=ctx.device)
+    t_off = 0
+    for (lo, hi, own0, own1), sdf, (nc, ne, nt), (cb, eb) in zip(ranges, grids, counts, bases):
+        ctx.mc_count(sdf, iso, z_offset=lo, nz_global=nz, own=(own0, own1))
+        pv, pt = ctx.mc_emit(sdf_params, centre_base=cb, edge_base=eb, sort=False)
+        gv[cb:cb + nc] = pv[:nc]
+        gv[eb:eb + ne] = pv[nc:]
+        gt[t_off:t_off + nt] = pt
+        t_off += nt
+    if t_total:
+        ctx.sort_triangles(gt, max(v_total, 1))
+    return gv, gt
