@@ -182,18 +182,24 @@ __device__ __forceinline__ unsigned point_flags_code(const float* __restrict__ s
   unsigned flags = 0;
   const bool has[3] = {hx, hy, hz};
   const float cn[3] = {c[1], c[3], c[4]};
-#pragma unroll
-  for (int dir = 0; dir < 3; ++dir) {
-    if (!has[dir]) continue;
-    if (__fmul_rn(c[0], cn[dir]) <= 0.0f) {  // B.4
-      bool live = ((c[0] > 0.0f) != (cn[dir] > 0.0f)) || underflow_edge_live(sdf, d, i, j, k, dir);
-      if (live) flags |= 1u << dir;
-    }
-  }
   unsigned cd = 0;
   if (hx && hy && hz) {
 #pragma unroll
     for (int v = 0; v < 8; ++v) cd |= (unsigned)(c[v] > 0.0f) << v;
+  }
+  // An edge owns a vertex iff one of the (up to four) voxels around it is active (B.4: vertices are created by the
+  // voxels that emit).  A sign change makes every voxel around the edge mixed, and a mixed voxel is active unless its
+  // ambiguity lookup is impossible (sub < 0, B.3) -- which the tables allow only for the two fully alternating codes
+  // 90 and 165 (case 13).  So the point's own voxel settles it whenever it exists and is not one of those two;
+  // otherwise, and for same-sign products that underflowed to zero (B.9), the neighbours are classified.
+  const bool own_settles = hx && hy && hz && cd != 90u && cd != 165u;
+#pragma unroll
+  for (int dir = 0; dir < 3; ++dir) {
+    if (!has[dir]) continue;
+    if (__fmul_rn(c[0], cn[dir]) <= 0.0f) {  // B.4
+      bool live = (((c[0] > 0.0f) != (cn[dir] > 0.0f)) && own_settles) || underflow_edge_live(sdf, d, i, j, k, dir);
+      if (live) flags |= 1u << dir;
+    }
   }
   *code = cd;
   return flags;

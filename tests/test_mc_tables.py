@@ -75,3 +75,43 @@ def test_triangles_use_only_crossed_edges():
             assert (12 in ids) <= bool(has_c)
             if not has_c:
                 assert ids == crossed, (code, s)   # plain sub-tables use every crossed edge
+
+
+def test_impossible_ambiguity_entries_are_exactly_the_contradictory_case13_patterns():
+    """Over every (code, face/interior test outcome) the run-time can form -- 686 entries of the 15 x 64 table --
+    `sub < 0` (App. B.3 "internal error", the voxel emits nothing) occurs only for the fully alternating codes 90
+    and 165, and there exactly for the 18 outcomes in which one pair of opposite faces is joined through both faces
+    while another pair is separated on both.  With L_f = [product of the face's positive corners > product of its
+    negative corners], opposite faces satisfy L1*L3 = L2*L4 = L5*L6 (each equals the product of all eight
+    magnitudes), so no real corner values produce such an outcome; float32 rounding can, within a few ulps of a
+    four-way tie (tools/mc_bad_voxel_search.py, tests/test_gpu_mc_geometry.py).  mc.hip relies on "only 90 / 165"."""
+    import itertools
+    case, it = _table("DISN_MC_CASE"), _table("DISN_MC_INTERIOR_TEST")
+    ft = _table("DISN_MC_FACE_TESTS").reshape(256, 7)
+    amb = _table("DISN_MC_AMBIGUITY").reshape(15, 64)
+    fv = [(0, 1, 5, 4), (1, 2, 6, 5), (3, 2, 6, 7), (0, 3, 7, 4), (0, 1, 2, 3), (4, 5, 6, 7)]   # App. A.3
+    total, bad_codes = 0, {}
+    for code in range(256):
+        if case[code] == 0:
+            continue
+        bits = ft[code, 0] + (1 if it[code] else 0)
+        for a in range(1 << bits):
+            total += 1
+            if amb[case[code], a] < 0:
+                bad_codes.setdefault(code, []).append(a)
+    assert total == 686 and sorted(bad_codes) == [90, 165] and all(len(v) == 18 for v in bad_codes.values())
+    for code, bad in bad_codes.items():
+        pos = [(code >> v) & 1 for v in range(8)]
+        contradictory = set()
+        for L in itertools.product([False, True], repeat=6):       # L[f]: positives' product > negatives' product
+            a = 0
+            for t in range(1, 7):
+                f = int(ft[code, t])
+                face = abs(f) - 1
+                a_pos = pos[fv[face][0]] == 1
+                raw = L[face] if a_pos else not L[face]                # A*C > B*D, A = the face's first corner
+                a |= int((raw == (f > 0)) == a_pos) << (t - 1)
+            pairs = [(L[0], L[2]), (L[1], L[3]), (L[4], L[5])]
+            if any(x and y for x, y in pairs) and any(not x and not y for x, y in pairs):
+                contradictory.add(a)
+        assert contradictory == set(bad)
