@@ -56,6 +56,28 @@ def cpu_baseline(res, trans_mat, feats_np, gfeat_np, weights, iso, budget_s=12.0
     return net_pps, n1, dt1, mc
 
 
+def batch_res128(ctx, enc, n=13):
+    """BASELINE.json configs[3]: n views (one per category) through create_sdf.BatchMesher at sdf_res 128 -- encoder,
+    coarse median iso, decode, marching cubes, D2H and OBJ hand-off to the writer threads; wall time per view on
+    the submitting thread (files are written by the pool, off the critical path)."""
+    import tempfile
+    from disn_amd import create_sdf
+    with tempfile.TemporaryDirectory() as td:
+        bm = create_sdf.BatchMesher(ctx, enc, 128, 0.0, td, median_iso=True)
+        views = list(create_sdf.synthetic_views(n + 1))
+        bm.submit(views[0])                       # warm-up (allocations)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for v in views[1:]:
+            bm.submit(v)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        stats = bm.finish()
+    return {"views": n, "sdf_res": 128, "ms_per_view": dt / n * 1e3, "views_per_s": n / dt,
+            "faces_per_view": float(np.mean([s[2] for s in stats[1:]])),
+            "note": "wall per view incl. VGG encoder, coarse-grid median iso, decode, MC, D2H; OBJ text written by 4 pool threads"}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves as fresh children
     (one process per GPU under torch.distributed.run), BEFORE this process touches the GPU -- a process that has
@@ -184,7 +206,8 @@ def main():
                        "per_gpu_points_evaluated": local_pts, "halo": pipe.halo if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": "sdf_decode_mx" if args.decoder == "mixed" else "sdf_decode", "achieved": alg_tflops, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": alg_tflops / PEAK_BF16_TFLOPS, "traffic": None,
-                         "kernel_ms": dec_ms, "alg_flop_per_point": ALG_FLOP_PER_POINT,
+                         "kernel_ms": dec_ms, "launches_per_pass": 2 if args.decoder == "mixed" else 1,
+                         "alg_flop_per_point": ALG_FLOP_PER_POINT,
                          "executed_mfma_tflops_bf16_rate": mfma_tflops, "mfma_issue_frac": mfma_tflops / PEAK_BF16_TFLOPS},
         }
         if world == 1 and pipe.mc_events:
@@ -209,6 +232,8 @@ def main():
                 out["roofline"]["traffic_note"] = tr["note"]
         except (OSError, ValueError, KeyError):
             pass
+        if world == 1:
+            out.setdefault("other_kernels", {})["batch_res128"] = batch_res128(ctx, enc)
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(min(16, os.cpu_count() or 1))
             feats_np = [f.cpu().numpy() for f in feats]

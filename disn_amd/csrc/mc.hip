@@ -11,7 +11,7 @@
 //                 vertices, already in the reference's key order
 //   mc_triangles  block scan of triangle/centre counts -> triangles with final
 //                 indices (smallest first) + centre vertices
-//   tri_sort_*    LSD radix sort (8-bit digits: histogram, per-digit row scan,
+//   tri_sort_*    LSD radix sort on the first index + run ordering (8-bit digits: histogram, per-digit row scan,
 //                 stable scatter) -> lexicographic order
 // Algorithmic bytes: 4 B/grid point + 24 B/vertex + 12 B/triangle.
 // Compile with -ffp-contract=off: App. B specifies separately rounded
@@ -738,6 +738,31 @@ __global__ __launch_bounds__(BLK) void tri_sort_scatter(const int* __restrict__ 
   }
 }
 
+// After the stable sort on the first index: triangles with equal first index form short runs (a vertex is the
+// smallest index of at most its valence many triangles).  Each thread finds its run and its rank inside it by
+// (second, third, position) and writes the triple to its final place: the result is the full lexicographic order
+// with a third of the radix passes.  Work is the sum of squared run lengths -- fine for meshes, and still correct
+// (only slow) for inputs with long runs.
+__global__ __launch_bounds__(BLK) void tri_sort_ties(const int* __restrict__ in, int* __restrict__ out, unsigned long long n) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * BLK + threadIdx.x;
+  if (t >= n) return;
+  const int a = in[3 * t], b = in[3 * t + 1], c = in[3 * t + 2];
+  unsigned long long lo = t, hi = t + 1;
+  unsigned rank = 0;
+  while (lo > 0 && in[3 * (lo - 1)] == a) {
+    --lo;
+    const int b2 = in[3 * lo + 1], c2 = in[3 * lo + 2];
+    rank += (b2 < b) || (b2 == b && c2 <= c);          // equal triples keep their order (stable)
+  }
+  while (hi < n && in[3 * hi] == a) {
+    const int b2 = in[3 * hi + 1], c2 = in[3 * hi + 2];
+    rank += (b2 < b) || (b2 == b && c2 < c);
+    ++hi;
+  }
+  int* o = out + 3 * (lo + rank);
+  o[0] = a; o[1] = b; o[2] = c;
+}
+
 }  // namespace
 
 struct McState {
@@ -831,13 +856,14 @@ static int sort_tris_on(DisnCtx* ctx, int* tris, uint64_t n, uint64_t max_index,
   const unsigned nb = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
   int* a = tris;
   int* b = tmp;
-  for (int comp = 2; comp >= 0; --comp)
-    for (int ps = 0; ps < passes; ++ps) {
-      tri_sort_hist<<<nb, BLK, 0, stream>>>(a, n, comp, 8 * ps, hist, nb);
-      tri_sort_rowscan<<<256, BLK, 0, stream>>>(hist, nb, hist + (size_t)nb * 256);
-      tri_sort_scatter<<<nb, BLK, 0, stream>>>(a, b, n, comp, 8 * ps, hist, nb, hist + (size_t)nb * 256);
-      int* t = a; a = b; b = t;
-    }
+  for (int ps = 0; ps < passes; ++ps) {   // stable LSD radix sort on the first index only ...
+    tri_sort_hist<<<nb, BLK, 0, stream>>>(a, n, 0, 8 * ps, hist, nb);
+    tri_sort_rowscan<<<256, BLK, 0, stream>>>(hist, nb, hist + (size_t)nb * 256);
+    tri_sort_scatter<<<nb, BLK, 0, stream>>>(a, b, n, 0, 8 * ps, hist, nb, hist + (size_t)nb * 256);
+    int* t = a; a = b; b = t;
+  }
+  tri_sort_ties<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, stream>>>(a, b, n);   // ... then order the short runs
+  { int* t = a; a = b; b = t; }
   if (a != tris) DISN_HIP(ctx, hipMemcpyAsync(tris, a, n * 3 * sizeof(int), hipMemcpyDeviceToDevice, stream));
   DISN_HIP(ctx, hipGetLastError());
   return DISN_OK;
