@@ -220,7 +220,7 @@ def main():
                 "marching_cubes": {"bound": "hbm", "ms": mc_ms, "algorithmic_bytes": mc_bytes,
                                    "achieved": mc_bytes / (mc_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                    "frac": mc_bytes / (mc_ms * 1e-3) / 1e9 / 8000.0,
-                                   "note": "count + emit + 9-pass triangle sort, incl. the host sync that returns the counts"},
+                                   "note": "count + emit + triangle sort (radix on the first index + run ordering), incl. the host sync that returns the counts"},
                 "per_image_precompute": {"ms": img_ms, "note": "5 x resize to 137x137 + fp32 MFMA GEMM 18769x1472x512 + bias fold"},
             }
         # HBM-side traffic of the dominant kernel, measured separately with rocprofv3 PMC passes

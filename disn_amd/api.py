@@ -234,7 +234,8 @@ def read_dist(path):
 
 def read_narrowband_dist(path):
     """Narrow-band .n.dist (the reference tool's `-n` input) -> (res, bbox, dense grid [z,y,x], n_cells);
-    cells outside the band are +FLT_MAX."""
+    cells the file does not list read +FLT_MAX outside the surface and -FLT_MAX inside it (side taken from the
+    last listed cell passed on the way along +x from the box wall)."""
     lib = _lib.load()
     res, n = ctypes.c_int(), ctypes.c_int64()
     bb = np.empty(6, np.float64)

@@ -72,7 +72,13 @@ extern "C" int disn_read_ndist(const char* path, float* values, size_t n_values)
   if (rc != DISN_OK) return rc;
   const size_t n1 = (size_t)res + 1;
   if (n_values != n1 * n1 * n1) return DISN_E_ARG;
-  for (size_t q = 0; q < n_values; ++q) values[q] = 3.402823466e+38f;   // outside the band: exterior
+  // Cells that the file does not list lie outside the band.  The file carries no inside/outside flag of its own;
+  // they get the sign of the side they are on, which the band itself tells: walking a grid line in +x from the box
+  // wall (outside), the last listed cell passed says on which side of the surface we are.  Exterior cells read
+  // +FLT_MAX, interior cells -FLT_MAX, so no surface appears between a band cell and a missing neighbour.
+  const float unset = -0.0f;   // bit pattern 0x80000000 never occurs as a marker clash: listed values overwrite it
+  std::vector<unsigned char> listed(n_values, 0);
+  for (size_t q = 0; q < n_values; ++q) values[q] = unset;
   FILE* f = fopen(path, "rb");
   if (!f) return DISN_E_IO;
   bool ok = fseek(f, 64, SEEK_SET) == 0;
@@ -84,12 +90,23 @@ extern "C" int disn_read_ndist(const char* path, float* values, size_t n_values)
     for (size_t q = 0; ok && q < want; ++q) {
       const Rec& r = buf[q];
       if (r.i < 0 || r.j < 0 || r.k < 0 || (size_t)r.i >= n1 || (size_t)r.j >= n1 || (size_t)r.k >= n1) { ok = false; break; }
-      values[((size_t)r.k * n1 + r.j) * n1 + r.i] = r.d;
+      const size_t p = ((size_t)r.k * n1 + r.j) * n1 + r.i;
+      values[p] = r.d;
+      listed[p] = 1;
     }
     done += (int64_t)want;
   }
   fclose(f);
-  return ok ? DISN_OK : DISN_E_IO;
+  if (!ok) return DISN_E_IO;
+  for (size_t row = 0; row < n1 * n1; ++row) {
+    float fill = 3.402823466e+38f;
+    for (size_t i = 0; i < n1; ++i) {
+      const size_t p = row * n1 + i;
+      if (listed[p]) fill = values[p] < 0.0f ? -3.402823466e+38f : 3.402823466e+38f;
+      else values[p] = fill;
+    }
+  }
+  return DISN_OK;
 }
 
 // integer -> decimal, returns the end pointer (faces are most of an OBJ's lines; printf is the slow part)

@@ -85,7 +85,34 @@ def test_reference_narrowband_fixture_known_answer(tmp_path):
     p, z = _narrowband_file(tmp_path)
     res, bbox, grid, n = api.read_narrowband_dist(p)
     assert res == 64 and n == 69149 and np.array_equal(bbox, z["bbox"])
-    assert int((grid < 1e38).sum()) == 69149
+    assert int((np.abs(grid) < 1e38).sum()) == 69149
     r = mc.marching_cubes(grid, iso=0.0, bbox=tuple(bbox))
     assert (len(r["verts"]), r["n_tri"]) == tuple(z["expect_vt"]) == (3800, 7604)
     assert r["n_bad"] == 0 and fields.mesh_is_closed_manifold(r["tris"])
+
+
+def test_narrowband_missing_cells_take_the_sign_of_their_side(tmp_path):
+    """A narrow band (|d| < 2.5 h) of two spheres written as .n.dist: the reader returns -FLT_MAX for the missing
+    cells inside a sphere and +FLT_MAX outside, and the band grid meshes exactly like the full field."""
+    import struct
+    from disn_amd import api
+    res = 24
+    l = np.linspace(-1, 1, res + 1)
+    z, y, x = np.meshgrid(l, l, l, indexing="ij")
+    full = np.minimum(np.sqrt((x - 0.3) ** 2 + y ** 2 + z ** 2) - 0.45, np.sqrt((x + 0.45) ** 2 + y ** 2 + z ** 2) - 0.3)
+    full = full.astype(np.float32)
+    band = np.abs(full) < 2.5 * (2.0 / res)
+    k, j, i = np.nonzero(band)
+    p = str(tmp_path / "two_spheres.n.dist")
+    with open(p, "wb") as f:
+        f.write(struct.pack("<3i", -res, res, res) + struct.pack("<6d", -1, -1, -1, 1, 1, 1) + struct.pack("<i", len(i)))
+        rec = np.zeros(len(i), dtype=np.dtype([("i", "<i4"), ("j", "<i4"), ("k", "<i4"), ("d", "<f4")]))
+        rec["i"], rec["j"], rec["k"], rec["d"] = i, j, k, full[band]
+        f.write(rec.tobytes())
+    r, bbox, grid, n = api.read_narrowband_dist(p)
+    assert r == res and n == len(i)
+    assert np.array_equal(grid[band], full[band])
+    assert bool((grid[~band & (full < 0)] == -np.finfo(np.float32).max).all()) and int((~band & (full < 0)).sum()) > 50
+    assert bool((grid[~band & (full > 0)] == np.finfo(np.float32).max).all())
+    a, b = mc.marching_cubes(grid, iso=0.0), mc.marching_cubes(full, iso=0.0)
+    assert a["n_tri"] > 500 and np.array_equal(a["tris"], b["tris"]) and np.array_equal(a["verts"], b["verts"])
