@@ -202,6 +202,7 @@ def main():
     plans = {   # layer -> scheme; MFMA time relative to bf16x3 everywhere (pairs: f1c2 32, f1c3 256, f2c1 512, f2c2 256)
         "P_today  bf16x3 everywhere": {l: "bf16x3" for l in LAYERS},
         "P_mixed  f16+fp8c on f1c2/f1c3/f2c1, bf16x3 on f2c2": {"f1c2": "f16+fp8c", "f1c3": "f16+fp8c", "f2c1": "f16+fp8c", "f2c2": "bf16x3"},
+        "P_mixed16 f16+fp8c on f1c2/f1c3/f2c1, f16x3 on f2c2": {"f1c2": "f16+fp8c", "f1c3": "f16+fp8c", "f2c1": "f16+fp8c", "f2c2": "f16x3"},
         "P_mixedb f16+f8b  on f1c2/f1c3/f2c1, bf16x3 on f2c2": {"f1c2": "f16+f8b", "f1c3": "f16+f8b", "f2c1": "f16+f8b", "f2c2": "bf16x3"},
         "P_mixedh f16+f8b  on f1c2/f1c3/f2c1, f16x3 on f2c2": {"f1c2": "f16+f8b", "f1c3": "f16+f8b", "f2c1": "f16+f8b", "f2c2": "f16x3"},
         "P_allb   f16+f8b everywhere": {l: "f16+f8b" for l in LAYERS},
@@ -236,8 +237,8 @@ def main():
     report["worst_margin_over_weight_sets"] = worst
     report["passing_with_5x_margin"] = sorted([sc for sc in schemes if worst[sc] >= 5.0], key=lambda s: units[s])
     out = os.path.join(ROOT, "profiles", "precision_budget.json")
-    json.dump(report, open(out, "w"), indent=1)
     report["worst_plan_margin"] = {p: min(ws["plans"][p]["margin"] for ws in report["weight_sets"].values()) for p in plans}
+    json.dump(report, open(out, "w"), indent=1)
     print("plan margins:", {k: round(v, 1) for k, v in report["worst_plan_margin"].items()})
     print("worst margins:", {k: round(v, 1) for k, v in worst.items()})
     print("wrote", out)
