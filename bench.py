@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--res", type=int, default=0, help="sdf_res (default 256 at N=1, round(256*N^(1/3)) otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="skip the other_kernels.batch_res128 measurement "
+                    "(keeps a profile of this command to launches of the benchmark grid only)")
     ap.add_argument("--decoder", choices=("mixed", "bf16x3"), default="mixed",
                     help="decoder arithmetic (disn_sdf_set_decoder); both meet the 1e-4 parity tolerance")
     args = ap.parse_args()
@@ -232,7 +234,7 @@ def main():
                 out["roofline"]["traffic_note"] = tr["note"]
         except (OSError, ValueError, KeyError):
             pass
-        if world == 1:
+        if world == 1 and not args.no_batch:
             out.setdefault("other_kernels", {})["batch_res128"] = batch_res128(ctx, enc)
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(min(16, os.cpu_count() or 1))

@@ -13,7 +13,7 @@ def variant(name, s):
         nonlocal s
         assert s.count(a) >= 1, (name, a)
         s = s.replace(a, b) if count == 0 else s.replace(a, b, count)
-    if name == "base":
+    if name in ("base", "base_global"):
         pass
     elif name == "nodma":     # steady-state refill pieces not issued
         rep("  constexpr int J = (U + 16) & 31;\n  pipe.template dma_sub<J>();", "  constexpr int J = (U + 16) & 31;")
@@ -49,14 +49,22 @@ def main():
     names = sys.argv[1:] or ["base", "nodma", "noread", "nosync", "nocvt"]
     os.makedirs(OUT, exist_ok=True)
     src = open(os.path.join(CSRC, "sdf.hip")).read()
+    os.environ["SEG_LOCAL"] = "1"
     env = {"s": src}
     exec(open(os.path.join(ROOT, "tools", "seg_patch_mx.py")).read(), env)
     patched = env["s"]
     procs = []
     for n in names:
+        if n.endswith("_global"):
+            os.environ["SEG_LOCAL"] = "0"
+            env = {"s": src}
+            exec(open(os.path.join(ROOT, "tools", "seg_patch_mx.py")).read(), env)
+            patched_n = env["s"]
+        else:
+            patched_n = patched
         d = os.path.join("/tmp", "exp_mx", n)
         os.makedirs(d, exist_ok=True)
-        open(os.path.join(d, "sdf.hip"), "w").write(variant(n, patched))
+        open(os.path.join(d, "sdf.hip"), "w").write(variant(n, patched_n))
         cmd = ("/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -ffp-contract=off "
                "-I%s -c %s/sdf.hip -o %s/sdf.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o %s/libdisn_%s.so "
                "%s/abi.o %s/hostio.o %s/mc.o %s/sdf.o" % (CSRC, d, d, OUT, n, CSRC, CSRC, CSRC, d))

@@ -18,8 +18,14 @@ rep("  float part = 0.0f;\n", "  TICK(6)\n  float part = 0.0f;\n")
 rep("  part += __shfl_xor(part, 32, 64);\n", "  part += __shfl_xor(part, 32, 64);\n  TICK(7)\n")
 rep("  Ring8 rg;\n", "  for (int i = 0; i < 8; ++i) pipe.tacc[i] = 0;\n  pipe.twait = 0; pipe.twait2 = 0;\n  pipe.tlast = clock64();\n  long long w0 = wall_clock64();\n  Ring8 rg;\n")
 rep('''  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n}''', '''  __syncthreads();
-  if (blockIdx.x == 7 && threadIdx.x == 0) { for (int i = 0; i < 8; ++i) ((long long*)a.out)[i] = pipe.tacc[i]; ((long long*)a.out)[8] = wall_clock64() - w0; ((long long*)a.out)[9] = pipe.twait; ((long long*)a.out)[10] = pipe.twait2; }
+  if (LOCAL == (SEG_LOCAL != 0) && blockIdx.x == 7 && threadIdx.x == 0) { for (int i = 0; i < 8; ++i) ((long long*)a.out)[i] = pipe.tacc[i]; ((long long*)a.out)[8] = wall_clock64() - w0; ((long long*)a.out)[9] = pipe.twait; ((long long*)a.out)[10] = pipe.twait2; }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n}''')
 s = head + s
 # the f2c1 phase tick: after the 16 groups of each chain step
 rep("    });\n  };\n#pragma unroll 1", "    });\n    TICK(5)\n  };\n#pragma unroll 1")
+# which stream's kernel reports (the other launch is dropped for the global stream: it would overwrite the counters)
+import os as _os
+_loc = _os.environ.get("SEG_LOCAL", "1")
+rep("#define SCHED_FENCE()", "#define SEG_LOCAL %s\n#define SCHED_FENCE()" % _loc)
+if _loc == "0":
+    rep("    sdf_decode_mx<true><<<blocks, 256, MX_LDS_BYTES, stream>>>(a);    // out = g + l (scaled)", "")

@@ -22,10 +22,10 @@ for it in range(1):
     torch.cuda.synchronize()
     v = sdf.view(-1)[:22].view(torch.int64).cpu().tolist()
     wall, tw, tb = v[8], v[9], v[10]; v = v[:8]
-    print("mid-stage waits per tile: vmcnt %.0f cycles, barrier %.0f cycles (132 rendezvous per tile)" % (tw / 518, tb / 518))
+    print("mid-stage waits per tile: vmcnt %.0f cycles, barrier %.0f cycles (66 rendezvous per tile and stream)" % (tw / 518, tb / 518))
     tiles = 518
     tot = sum(v)
     print("total cycles", tot, "wall %.2f ms -> %.3f GHz" % (wall * 1e-5, tot / (wall * 1e-8) / 1e9))
     for n, c, st, idl in zip(names, v, stages, ideal):
-        per = c / tiles / (1 if n.startswith("start") else 2)
+        per = c / tiles
         print("%-24s %8.0f cyc/stream  %5.1f%%  %s" % (n, per, 100.0 * c / tot, ("%.0f cyc/stage (ideal %d)" % (per / st, idl)) if st else ""))
