@@ -47,6 +47,24 @@ class _Comm:
         self.dist.recv(c, src=src)
         t.copy_(c)
 
+    def exchange(self, sends, recvs):
+        """sends = [(tensor, dst)], recvs = [(tensor, src)] with contiguous device tensors (empty ones skipped).
+        RCCL: one batch of non-blocking point-to-point operations, so a rank's pieces from all peers travel at the
+        same time over their own xGMI links and land in their final place; gloo (rehearsals): one after the other."""
+        sends = [(t, d) for t, d in sends if t.numel()]
+        recvs = [(t, r) for t, r in recvs if t.numel()]
+        if self.host:
+            for t, d in sends:
+                self.send(t, d)
+            for t, r in recvs:
+                self.recv(t, r)
+            return
+        ops = [self.dist.P2POp(self.dist.isend, t, d) for t, d in sends]
+        ops += [self.dist.P2POp(self.dist.irecv, t, r) for t, r in recvs]
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+
 
 class MeshPipeline:
     def __init__(self, ctx, rank=0, world=1, dist=None, halo="exchange"):
@@ -143,29 +161,25 @@ class MeshPipeline:
         c_total = sum(c[0] for c in allc)
         v_total = c_total + sum(c[1] for c in allc)
         t_total = sum(c[2] for c in allc)
+        nc0, ne0, nt0 = allc[self.rank]
         if self.rank != 0:
-            for t in (verts, tris):
-                if t.numel():
-                    self.dist.send(t, dst=0)
+            # three pieces, each contiguous at the receiver: centre vertices, edge vertices, triangles
+            self.dist.exchange([(verts[:nc0], 0), (verts[nc0:], 0), (tris, 0)], [])
             return None, None
         gv = torch.empty((v_total, 3), dtype=torch.float64, device=ctx.device)
         gt = torch.empty((t_total, 3), dtype=torch.int32, device=ctx.device)
-        t_off = 0
+        recvs, t_off = [], 0
         for r in range(self.world):
             nc, ne, nt = allc[r]
             cbr, ebr = bases[r]
             if r == 0:
-                pv, pt = verts, tris
+                gv[cbr:cbr + nc] = verts[:nc]          # centre vertices: slabs in reverse order
+                gv[ebr:ebr + ne] = verts[nc:]          # edge vertices: slab order
+                gt[t_off:t_off + nt] = tris
             else:
-                pv = torch.empty((nc + ne, 3), dtype=torch.float64, device=ctx.device)
-                pt = torch.empty((nt, 3), dtype=torch.int32, device=ctx.device)
-                for t in (pv, pt):
-                    if t.numel():
-                        self.dist.recv(t, src=r)
-            gv[cbr:cbr + nc] = pv[:nc]            # centre vertices: slabs in reverse order
-            gv[ebr:ebr + ne] = pv[nc:]            # edge vertices: slab order
-            gt[t_off:t_off + nt] = pt
+                recvs += [(gv[cbr:cbr + nc], r), (gv[ebr:ebr + ne], r), (gt[t_off:t_off + nt], r)]
             t_off += nt
+        self.dist.exchange([], recvs)
         if t_total:
             ctx.sort_triangles(gt, max(v_total, 1))
         return gv, gt

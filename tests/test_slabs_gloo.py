@@ -74,3 +74,48 @@ def test_slab_ranges_cover_and_halo():
             for (lo, hi, o0, o1), (g0, g1) in zip(rs, own):
                 assert lo <= max(0, g0 - 1) and hi >= min(nz, g1 + 2)      # one plane below, two above
             assert split_layers(nz, n)[-1] == nz - 1
+
+
+def _exchange_worker(rank, world, port, tmp):
+    """pipeline._Comm.exchange in its non-blocking form (the one RCCL runs: one batch of isend / irecv into the final
+    row ranges), here over gloo with host tensors."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from disn_amd.pipeline import _Comm
+    comm = _Comm(dist)
+    comm.host = False                      # tensors are already on the host: take the batched path
+    sizes = [(3 + r, 5 * r, 2 * r + 1) for r in range(world)]          # (centres, edges, triangles) per rank
+    nc, ne, nt = sizes[rank]
+    verts = torch.arange((nc + ne) * 3, dtype=torch.float64).reshape(-1, 3) + 1000.0 * rank
+    tris = torch.arange(nt * 3, dtype=torch.int32).reshape(-1, 3) + 100 * rank
+    if rank != 0:
+        comm.exchange([(verts[:nc], 0), (verts[nc:], 0), (tris, 0)], [])
+    else:
+        c_total = sum(s[0] for s in sizes)
+        gv = torch.full((c_total + sum(s[1] for s in sizes), 3), -1.0, dtype=torch.float64)
+        gt = torch.full((sum(s[2] for s in sizes), 3), -1, dtype=torch.int32)
+        recvs, c_off, e_off, t_off, want_v, want_t = [], 0, c_total, 0, gv.clone(), gt.clone()
+        for r in range(world):
+            rc, re_, rt = sizes[r]
+            v_r = torch.arange((rc + re_) * 3, dtype=torch.float64).reshape(-1, 3) + 1000.0 * r
+            t_r = torch.arange(rt * 3, dtype=torch.int32).reshape(-1, 3) + 100 * r
+            want_v[c_off:c_off + rc], want_v[e_off:e_off + re_], want_t[t_off:t_off + rt] = v_r[:rc], v_r[rc:], t_r
+            if r == 0:
+                gv[c_off:c_off + rc], gv[e_off:e_off + re_], gt[t_off:t_off + rt] = verts[:rc], verts[rc:], tris
+            else:
+                recvs += [(gv[c_off:c_off + rc], r), (gv[e_off:e_off + re_], r), (gt[t_off:t_off + rt], r)]
+            c_off, e_off, t_off = c_off + rc, e_off + re_, t_off + rt
+        comm.exchange([], recvs)
+        open(tmp, "w").write("ok" if torch.equal(gv, want_v) and torch.equal(gt, want_t) else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_batched_mesh_gather_lands_in_place(world, tmp_path):
+    port = 31500 + os.getpid() % 2000 + world
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_exchange_worker, args=(world, port, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
