@@ -967,25 +967,13 @@ __device__ __forceinline__ void group_step_x(Pipe& pipe, Ring8& rg, Acc& acc, co
   unit_refill<U + 3>(pipe, rg);
   extra(gap<3>{});
   SCHED_FENCE();
-#if defined(MX_DEBUG_E0_ZEROA)
-  { intx8 z = {0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("" : "+v"(z)); mfma_fp8<AGPR>(acc, z, xg_x8(x), sc.w, sc.xl); }
-#elif defined(MX_DEBUG_E0_ZEROB)
-  { intx8 z = {0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("" : "+v"(z)); mfma_fp8<AGPR>(acc, rg.e[0], z, sc.w, sc.xl); }
-#elif defined(MX_DEBUG_E0_BXL)
-  mfma_fp8<AGPR>(acc, rg.e[0], xl8, sc.w, sc.xl);
-#elif defined(MX_DEBUG_E0_AE1)
-  mfma_fp8<AGPR>(acc, rg.e[1], xg_x8(x), sc.w, sc.xl);
-#elif !defined(MX_DEBUG_NO_E0)
   mfma_fp8<AGPR>(acc, rg.e[0], xg_x8(x), sc.w, sc.xl);
-#endif
   SCHED_FENCE();
   unit_refill<U + 4>(pipe, rg);
   unit_refill<U + 5>(pipe, rg);
   extra(gap<4>{});
   SCHED_FENCE();
-#ifndef MX_DEBUG_NO_E1
   mfma_fp8<AGPR>(acc, rg.e[1], xl8, sc.w, sc.xl);
-#endif
   SCHED_FENCE();
   unit_refill<U + 6>(pipe, rg);
   unit_refill<U + 7>(pipe, rg);
