@@ -4,6 +4,9 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import disn_amd._lib as _lib
+if os.environ.get('SEG_LIB'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['SEG_LIB'])
 from disn_amd.api import Context
 
 
