@@ -1232,14 +1232,13 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
                                                 const float* b4 /*LDS: global stream's fold2/conv1 bias*/, uint4* park,
                                                 const float* __restrict__ pmap, float px, float py, float pz, float u,
                                                 float v) {
-  // h = lane >> 5 is recomputed from the DMA offset register at every use: addresses derived from a long-lived h
+  // half_of() = lane >> 5, recomputed from the DMA offset register at every use: addresses derived from a long-lived copy
   // cost registers that this kernel does not have
   auto half_of = [&]() {
     unsigned vo = pipe.voff;
     asm volatile("" : "+v"(vo));
     return (int)(vo >> 7);
   };
-#define h half_of()
   // fold2/conv1 accumulators: bias (+ image term), exactly as in the bf16 kernel
   floatx16 acc4[16];
   Corners cn;
@@ -1252,7 +1251,7 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
     auto gather = [&](floatx4 (&dst)[16], int nb4) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float* src = pmap + (size_t)cn.pix[c] * 512 + 32 * nb4 + 4 * h;
+        const float* src = pmap + (size_t)cn.pix[c] * 512 + 32 * nb4 + 4 * half_of();
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[4 * c + q] = *(const floatx4*)(src + 8 * q);
       }
@@ -1279,7 +1278,7 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
   } else {
 #pragma unroll
     for (int nb4 = 0; nb4 < 16; ++nb4) {
-      acc4[nb4] = bias_init(b4, 32 * nb4, h);
+      acc4[nb4] = bias_init(b4, 32 * nb4, half_of());
       asm volatile("" : "+a"(acc4[nb4]));
     }
   }
@@ -1289,7 +1288,7 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
   XG x1;
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
-    const int f = (g & 3) + 8 * (g >> 2) + 4 * h;
+    const int f = (g & 3) + 8 * (g >> 2) + 4 * half_of();
     floatx4 wa = *(const floatx4*)(sp + SP_W1 + 4 * f);
     floatx4 wb = *(const floatx4*)(sp + SP_W1 + 4 * (32 + f));
     x1.a[g] = __float_as_int(fmaf(pz, wa[2], fmaf(py, wa[1], px * wa[0])) + wa[3]);
@@ -1303,10 +1302,10 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
     asm volatile("s_nop 7" ::: "memory");   // the split of h1 was written by VALU conversions just above
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      h2[2 * st].a = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 0), h));
-      h2[2 * st].b = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 1), h));
-      h2[2 * st + 1].a = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 2), h));
-      h2[2 * st + 1].b = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 3), h));
+      h2[2 * st].a = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 0), half_of()));
+      h2[2 * st].b = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 1), half_of()));
+      h2[2 * st + 1].a = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 2), half_of()));
+      h2[2 * st + 1].b = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 3), half_of()));
       group_step<0, false>(pipe, rg, h2[2 * st].a, x1, sc, [](auto) {});
       group_step<1, false>(pipe, rg, h2[2 * st].b, x1, sc, [](auto) {});
       group_step<2, false>(pipe, rg, h2[2 * st + 1].a, x1, sc, [](auto) {});
@@ -1325,9 +1324,9 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
   // their in-place split fills the shadows of the K=64 MFMAs.
   const Scales sc3 = {load_scale(sp, 1), xl_scale}, sc4 = {load_scale(sp, 2), xl_scale};
   XG xc;
-  xc.a = as_bits(bias_init(sp + SP_B3, 0, h));
+  xc.a = as_bits(bias_init(sp + SP_B3, 0, half_of()));
   asm volatile("s_nop 7" ::: "memory");
-  l3_stage_mx(pipe, rg, xc.a, h2, park, sc3, [&] { xc.b = as_bits(bias_init(sp + SP_B3, 32, h)); });
+  l3_stage_mx(pipe, rg, xc.a, h2, park, sc3, [&] { xc.b = as_bits(bias_init(sp + SP_B3, 32, half_of())); });
   l3_stage_mx(pipe, rg, xc.b, h2, park, sc3, [] {});
   drain_v(xc.b);
   drain_v(xc.b);
@@ -1341,7 +1340,7 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
   // (k-steps 0, 1 were read by MFMAs 0, 1; the fp8 operand a[8..15] by MFMA 4, which has finished when MFMA 5,
   // chained on the same accumulator, has issued).
   XG xd;
-  xd.a = as_bits(bias_init(sp + SP_B3, 64, h));
+  xd.a = as_bits(bias_init(sp + SP_B3, 64, half_of()));
   auto chain = [&](XG& cu, XG& nx, const int m, auto with_next, auto with_pre) {
     constexpr bool NEXT = decltype(with_next)::value, PRE = decltype(with_pre)::value;
     if constexpr (NEXT) {
@@ -1382,7 +1381,7 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
   // the accumulator file cannot be indexed by a loop counter)
   floatx16 acc5[8];
 #pragma unroll
-  for (int nb = 0; nb < 8; ++nb) acc5[nb] = bias_init(sp + SP_B5, 32 * nb, h);
+  for (int nb = 0; nb < 8; ++nb) acc5[nb] = bias_init(sp + SP_B5, 32 * nb, half_of());
   intx4 yhi[2][2], ylo[2][2];
   CvtBf cs5;
   drain_a(acc4[0]);
@@ -1405,14 +1404,13 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
     drain_v(acc5[nb]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      floatx4 w = *(const floatx4*)(sp + SP_W6 + 32 * nb + 8 * q + 4 * h);
+      floatx4 w = *(const floatx4*)(sp + SP_W6 + 32 * nb + 8 * q + 4 * half_of());
 #pragma unroll
       for (int e = 0; e < 4; ++e) part = fmaf(fmaxf(acc5[nb][4 * q + e], 0.0f), w[e], part);
     }
   }
   part += __shfl_xor(part, 32, 64);
   return part + sp[SP_B6];
-#undef h
 }
 
 // One launch per stream: LOCAL = false evaluates the global stream and stores its raw value g, LOCAL = true the local
