@@ -130,7 +130,7 @@ def test_state_errors(ctx):
 
 
 @pytest.mark.parametrize("decoder", ["mixed", "bf16x3"])
-@pytest.mark.parametrize("res,z0,z1", [(3, 0, 3), (7, 0, 7), (8, 0, 8), (12, 1, 11), (20, 0, 3), (33, 5, 5),
+@pytest.mark.parametrize("res,z0,z1", [(1, 0, 1), (2, 1, 2), (3, 0, 3), (7, 0, 7), (8, 0, 8), (12, 1, 11), (20, 0, 3), (33, 5, 5),
                                         (40, 0, 40), (64, 0, 64), (64, 7, 38)])
 def test_grid_tiling_matches_points_mode(ctx, model, decoder, res, z0, z1):
     """The grid is walked in bricks of 8 x 4 x 4 points (super-bricks for L2 locality) plus three linear remainder
