@@ -16,6 +16,11 @@ class DisnDecoderWeights(ctypes.Structure):
     _fields_ = [(n, ctypes.POINTER(ctypes.c_float)) for n in _names]
 
 
+class DisnVggWeights(ctypes.Structure):
+    _fields_ = [("conv_w", ctypes.POINTER(ctypes.c_float) * 13), ("conv_b", ctypes.POINTER(ctypes.c_float) * 13),
+                ("fc_w", ctypes.POINTER(ctypes.c_float) * 3), ("fc_b", ctypes.POINTER(ctypes.c_float) * 3)]
+
+
 class DisnMcGrid(ctypes.Structure):
     _fields_ = [("nx", ctypes.c_int32), ("ny", ctypes.c_int32), ("nz", ctypes.c_int32),
                 ("z_offset", ctypes.c_int32), ("nz_global", ctypes.c_int32),
@@ -36,6 +41,8 @@ SIGNATURES = {
     "disn_project_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "disn_resize_bilinear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "disn_sample_features": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "disn_vgg_set_weights": (c_int, [c_void_p, c_int, ctypes.POINTER(DisnVggWeights)]),
+    "disn_vgg_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
     "disn_mc_count": (c_int, [c_void_p, c_void_p, ctypes.POINTER(DisnMcGrid), c_float,
                               ctypes.POINTER(c_uint64), c_void_p]),
     "disn_mc_emit": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

@@ -153,7 +153,7 @@ class BatchMesher:
         trans_mat = view["trans_mat"]
         if self.cam is not None:
             from . import camera
-            emb, _ = self.cam[0](view["img"])
+            emb, _ = self.cam[0](view["img"], feats=False)
             trans_mat = camera.pred_trans_mat(emb, self.cam[1])[0].cpu().numpy()
         params = tuple(float(v) for v in view["sdf_params"])
         iso = self.iso
@@ -230,13 +230,13 @@ def main(argv=None):
         from . import camera
         if random_init:
             log("create_sdf: --random_init -> seeded random-init camera network")
-            cam = (Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed + 1)), camera.random_weights(FLAGS.seed))
+            cam = (Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed + 1), slot=1), camera.random_weights(FLAGS.seed))
         else:
             cam_ckpt = tf_bundle.latest_checkpoint(FLAGS.cam_log_dir)
             if cam_ckpt is None:
                 raise SystemExit("create_sdf: no checkpoint under --cam_log_dir %s (give --random_init to run on "
                                  "random weights)" % FLAGS.cam_log_dir)
-            cam = (Vgg16Encoder(ctx, tf_bundle.vgg_weights(cam_ckpt)), tf_bundle.camera_weights(cam_ckpt))
+            cam = (Vgg16Encoder(ctx, tf_bundle.vgg_weights(cam_ckpt), slot=1), tf_bundle.camera_weights(cam_ckpt))
 
     if FLAGS.synthetic:
         views = synthetic_views(FLAGS.synthetic)

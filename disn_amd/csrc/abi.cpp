@@ -23,6 +23,7 @@ extern "C" void disn_destroy(DisnCtx* ctx) {
   (void)hipSetDevice(ctx->device);
   disn_sdf_state_free(ctx);
   disn_mc_state_free(ctx);
+  disn_vgg_state_free(ctx);
   delete ctx;
 }
 

@@ -17,12 +17,14 @@ struct DevBuf {
 
 struct SdfState;  // sdf.hip
 struct McState;   // mc.hip
+struct VggState;  // vgg.hip
 
 struct DisnCtx {
   int device = 0;
   std::string err;
   SdfState* sdf = nullptr;
   McState* mc = nullptr;
+  VggState* vgg = nullptr;
   void* static_scratch = nullptr;   // this device's copy of mc.hip's static scratch array (disn_mc_static_init)
 };
 
@@ -70,6 +72,7 @@ inline void disn_release(DevBuf& b) {
 
 void disn_sdf_state_free(DisnCtx*);
 void disn_mc_state_free(DisnCtx*);
+void disn_vgg_state_free(DisnCtx*);
 int disn_mc_static_init(DisnCtx*);   // mc.hip: looks up the device address of the static scratch array
 
 // ---- device helpers (wave = 64 lanes) ------------------------------------

@@ -99,7 +99,7 @@ def main(argv=None):
                                  "weights)" % FLAGS.cam_log_dir)
             log("Model loading from %s" % cam_ckpt)
             cam_vgg, cam_w = tf_bundle.vgg_weights(cam_ckpt), tf_bundle.camera_weights(cam_ckpt)
-        cam_emb, _ = Vgg16Encoder(ctx, cam_vgg)(img)
+        cam_emb, _ = Vgg16Encoder(ctx, cam_vgg, slot=1)(img, feats=False)
         trans_mat = camera.pred_trans_mat(cam_emb, cam_w)[0].cpu().numpy()
         log("pred_trans_mat_val", trans_mat)
     else:
@@ -119,7 +119,7 @@ def main(argv=None):
         feats, gfeat = pipe._broadcast_features(feats, gfeat)
         ctx.set_image(feats, gfeat)
         iso = coarse_median_iso(ctx, trans_mat, sdf_params)
-        log("demo: --random_init without --iso: using the median of a coarse whole-box grid, %.6g "
+        log("demo: --random_init without --iso: using the median of a coarse whole-box grid, %.9g "
             "(random weights have no zero level set)" % iso)
     torch.cuda.synchronize()
     t1 = time.time()

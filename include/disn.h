@@ -127,6 +127,29 @@ int disn_resize_bilinear(DisnCtx* ctx, const float* in, int ih, int iw, int c, f
  * maps cached by disn_sdf_set_image.  feat_out float[n][1472]. */
 int disn_sample_features(DisnCtx* ctx, const float* xy, int64_t n, float* feat_out, void* stream);
 
+/* ---- once-per-image VGG-16 encoder (not the hot path) -- */
+/* The slim vgg_16 variable set in the TensorFlow layout (HWIO): conv_w[i] = [3][3][Cin][Cout] of
+ * conv1_1, conv1_2, conv2_1, ... conv5_3 (Cout 64,64,128,128,256,256,256,512 x6), conv_b[i] = [Cout];
+ * fc_w = fc6 [7][7][512][4096], fc7 [1][1][4096][4096], fc8 [1][1][4096][1024] with their biases
+ * (reference layer list: models/CNN/vgg.py:182-218).  HOST pointers; copied and packed. */
+typedef struct DisnVggWeights {
+  const float* conv_w[13];
+  const float* conv_b[13];
+  const float* fc_w[3];
+  const float* fc_b[3];
+} DisnVggWeights;
+/* Replaces Saver.restore of the vgg_16 variables (reference demo/demo.py:153-165 for the SDF network,
+ * :236-241 for the camera network).  slot 0 = SDF encoder, slot 1 = camera-estimator encoder.  Synchronous. */
+int disn_vgg_set_weights(DisnCtx* ctx, int slot, const DisnVggWeights* w);
+/* Replaces the encoder half of the graph (reference models/model_normalization.py:65-78;
+ * cam_est/model_cam_old.py:70-78): img = DEVICE float[img_h][img_w][3], values in [0,1], BGR order, no mean
+ * subtraction (demo/demo.py:263-264) -> TF1 legacy bilinear resize to 224x224 -> 13 x (conv3x3 SAME + ReLU),
+ * 5 x maxpool 2x2, fc6 7x7 VALID + ReLU, fc7 + ReLU, fc8.  Exact fp32 with a fixed summation order
+ * (deterministic run to run).  feat_maps: five DEVICE output buffers in the layout disn_sdf_set_image reads
+ * (NHWC [224,224,64] ... [14,14,512]) or NULL (entries may be NULL too); global_feat: DEVICE float[1024] or NULL. */
+int disn_vgg_forward(DisnCtx* ctx, int slot, const float* img, int img_h, int img_w, float* const feat_maps[5],
+                     float* global_feat, void* stream);
+
 /* ---- marching cubes ---------------------------------------------------- */
 /* Slab description.  A whole grid is {nx,ny,nz, 0, nz, 0, nz}. */
 typedef struct DisnMcGrid {

@@ -49,6 +49,47 @@ def test_config0_chair_res64(ctx):
     assert np.array_equal(verts.cpu().numpy(), ref["verts"])
 
 
+def test_config1_res256_full(ctx):
+    """BASELINE.json configs[1], the configuration the metric is quoted on: chair image, sdf_res 256 (16 974 593 points),
+    two-stream decoder, full sorted mesh through MeshPipeline.run (reference demo/demo.py:281-369)."""
+    from disn_amd import demo, synth
+    from disn_amd.encoder import Vgg16Encoder
+    from disn_amd.pipeline import MeshPipeline, coarse_median_iso
+    img = demo.read_image(os.path.join(ROOT, "tests", "golden", "demo_chair_20.png"))
+    w = synth.decoder_weights(seed=0)
+    ctx.set_weights(w)
+    gfeat, feats = Vgg16Encoder(ctx, synth.vgg_weights(seed=0))(img)
+    ctx.set_image(feats, gfeat)
+    iso = coarse_median_iso(ctx, synth.GT_TRANS_MAT, res=64)
+    pipe = MeshPipeline(ctx)
+    verts, tris = pipe.run(feats, gfeat, synth.GT_TRANS_MAT, 256, iso)
+    sdf = pipe.last_sdf
+    assert tuple(sdf.shape) == (257, 257, 257)
+    # every second point of every second plane is the sdf_res-128 grid (linspace end and mid points are exact)
+    coarse = ctx.sdf_grid(synth.GT_TRANS_MAT, 128)
+    assert torch.equal(sdf[::2, ::2, ::2], coarse)
+    del coarse
+    # 250 000 sampled points against the float64 oracle
+    got = sdf.cpu().numpy()
+    maps = [f.cpu().numpy() for f in feats]
+    rng = np.random.default_rng(256)
+    idx = rng.integers(0, 257, (250000, 3))
+    ax = np.linspace(-1, 1, 257)
+    pts = np.stack([ax[idx[:, 0]], ax[idx[:, 1]], ax[idx[:, 2]]], -1).astype(np.float32)
+    want = net.sdf_points(pts, pts, synth.GT_TRANS_MAT, maps, gfeat.cpu().numpy(), w, dtype=torch.float64) / 10.0
+    err = float(np.abs(got[idx[:, 2], idx[:, 1], idx[:, 0]] - want).max())
+    print("res 256: max |gpu - oracle| = %.2e on %d sampled points" % (err, len(idx)))
+    assert err <= TOL_SDF
+    # the mesh of the GPU's own grid, bit-exact against the oracle's marching cubes
+    ref = mc.marching_cubes(got, iso=iso)
+    t = tris.cpu().numpy()
+    print("res 256: %d vertices, %d triangles" % (len(ref["verts"]), ref["n_tri"]))
+    assert ref["n_tri"] > 100000
+    assert np.array_equal(t, ref["tris"])
+    assert np.array_equal(verts.cpu().numpy(), ref["verts"])
+    assert _lex_sorted(t) and int(t.max()) < len(verts) and int(t.min()) == 0
+
+
 def _slabs_equal_single_pass(ctx, res, nslabs, seed):
     from disn_amd import synth
     from disn_amd.pipeline import coarse_median_iso, mesh_by_slabs
