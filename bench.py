@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALG_FLOP_PER_POINT = 3671808        # SURVEY.md s8d (global term hoisted)
+EXECUTED_FLOP_PER_POINT = 2 * 2 * (64 * 256 + 256 * 512 + 512 * 512 + 512 * 256)   # MFMA layers actually run (image term pre-projected per pixel)
 # MFMA pipe time per point in bf16-rate flops (2 streams x 2 flop/MAC): the bf16x3 decoder runs 3 bf16 products per
 # layer; the mixed decoder 1 f16 product + 2 fp8 products at twice the rate (= 2 units) on fold1/conv2, fold1/conv3
 # and fold2/conv1, and the bf16 triple on fold2/conv2
@@ -202,14 +203,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE[args.decoder], "data": "synthetic",
-            "config": {"workload": "sdf_res=%d two-stream, full sorted mesh output, %d z-slab(s)" % (res, world),
+            "config": {"workload": "sdf_res=%d two-stream, full sorted mesh output in HBM, %d z-slab(s); device->host copy and "
+                                   "OBJ text excluded (other_kernels.mesh_output)" % (res, world),
                        "sdf_res": res, "decoder": args.decoder, "points": points, "mesh_vertices": int(verts.shape[0]),
                        "mesh_triangles": int(tris.shape[0]), "iso": iso,
                        "per_gpu_points_evaluated": local_pts, "halo": pipe.halo if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": "sdf_decode_mx" if args.decoder == "mixed" else "sdf_decode", "achieved": alg_tflops, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": alg_tflops / PEAK_BF16_TFLOPS, "traffic": None,
                          "kernel_ms": dec_ms, "launches_per_pass": 2 if args.decoder == "mixed" else 1,
-                         "alg_flop_per_point": ALG_FLOP_PER_POINT,
+                         "alg_flop_per_point": ALG_FLOP_PER_POINT, "executed_flop_per_point": EXECUTED_FLOP_PER_POINT,
                          "executed_mfma_tflops_bf16_rate": mfma_tflops, "mfma_issue_frac": mfma_tflops / PEAK_BF16_TFLOPS},
         }
         if world == 1 and pipe.mc_events:
@@ -225,6 +227,22 @@ def main():
                                    "note": "count + emit + triangle sort (radix on the first index + run ordering), incl. the host sync that returns the counts"},
                 "per_image_precompute": {"ms": img_ms, "note": "5 x resize to 137x137 + fp32 MFMA GEMM 18769x1472x512 + bias fold"},
             }
+        if world == 1:
+            # what follows the timed region when the caller wants result.obj (reference demo/demo.py:355-369)
+            import tempfile
+            from disn_amd import api
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            vh, th = verts.cpu().numpy(), tris.cpu().numpy()
+            t2 = time.perf_counter()
+            with tempfile.TemporaryDirectory() as td:
+                api.write_obj(os.path.join(td, "result.obj"), vh, th)
+                t3 = time.perf_counter()
+                obj_bytes = os.path.getsize(os.path.join(td, "result.obj"))
+            out.setdefault("other_kernels", {})["mesh_output"] = {
+                "d2h_ms": (t2 - t1) * 1e3, "obj_write_ms": (t3 - t2) * 1e3, "obj_bytes": obj_bytes,
+                "note": "NOT in ms_per_step: copy of the sorted mesh to pageable host memory, then disn_write_obj "
+                        "(multi-threaded text formatting) into a temporary directory"}
         # HBM-side traffic of the dominant kernel, measured separately with rocprofv3 PMC passes
         # (tools/pmc_decode.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md) and committed under profiles/
         try:

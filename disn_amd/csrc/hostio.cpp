@@ -73,12 +73,16 @@ extern "C" int disn_read_ndist(const char* path, float* values, size_t n_values)
   const size_t n1 = (size_t)res + 1;
   if (n_values != n1 * n1 * n1) return DISN_E_ARG;
   // Cells that the file does not list lie outside the band.  The file carries no inside/outside flag of its own;
-  // they get the sign of the side they are on, which the band itself tells: walking a grid line in +x from the box
-  // wall (outside), the last listed cell passed says on which side of the surface we are.  Exterior cells read
-  // +FLT_MAX, interior cells -FLT_MAX, so no surface appears between a band cell and a missing neighbour.
-  const float unset = -0.0f;   // bit pattern 0x80000000 never occurs as a marker clash: listed values overwrite it
-  std::vector<unsigned char> listed(n_values, 0);
-  for (size_t q = 0; q < n_values; ++q) values[q] = unset;
+  // they get the sign of the side they are on, which the band itself tells (it is assumed closed and iso ~ 0):
+  // along a grid line a missing cell has the sign of the last listed cell passed, and the cells in front of the
+  // line's first listed cell have that cell's sign (so a line that starts inside the surface at the box wall is
+  // interior up to its first band cell).  Lines without any listed cell are resolved the same way along y, then
+  // along z, from the cells resolved so far.  Exterior cells read +FLT_MAX, interior cells -FLT_MAX, so no
+  // surface appears between a band cell and a missing neighbour.
+  const float FMAX = 3.402823466e+38f;
+  std::vector<uint64_t> known((n_values + 63) / 64, 0);   // bit p: values[p] is listed or already resolved
+  auto is_known = [&](size_t p) { return (known[p >> 6] >> (p & 63)) & 1u; };
+  auto set_known = [&](size_t p) { known[p >> 6] |= (uint64_t)1 << (p & 63); };
   FILE* f = fopen(path, "rb");
   if (!f) return DISN_E_IO;
   bool ok = fseek(f, 64, SEEK_SET) == 0;
@@ -92,21 +96,66 @@ extern "C" int disn_read_ndist(const char* path, float* values, size_t n_values)
       if (r.i < 0 || r.j < 0 || r.k < 0 || (size_t)r.i >= n1 || (size_t)r.j >= n1 || (size_t)r.k >= n1) { ok = false; break; }
       const size_t p = ((size_t)r.k * n1 + r.j) * n1 + r.i;
       values[p] = r.d;
-      listed[p] = 1;
+      set_known(p);
     }
     done += (int64_t)want;
   }
   fclose(f);
   if (!ok) return DISN_E_IO;
-  for (size_t row = 0; row < n1 * n1; ++row) {
-    float fill = 3.402823466e+38f;
-    for (size_t i = 0; i < n1; ++i) {
-      const size_t p = row * n1 + i;
-      if (listed[p]) fill = values[p] < 0.0f ? -3.402823466e+38f : 3.402823466e+38f;
-      else values[p] = fill;
+  // one sweep per axis: lines of `len` cells, cell t of line l at base(l) + t * stride
+  auto sweep = [&](size_t stride, size_t nlines, auto base) {
+    for (size_t l = 0; l < nlines; ++l) {
+      const size_t b0 = base(l);
+      size_t first = n1;
+      for (size_t t = 0; t < n1; ++t)
+        if (is_known(b0 + t * stride)) { first = t; break; }
+      if (first == n1) continue;   // nothing to go by on this line (yet)
+      float fill = values[b0 + first * stride] < 0.0f ? -FMAX : FMAX;
+      for (size_t t = 0; t < n1; ++t) {
+        const size_t p = b0 + t * stride;
+        if (is_known(p)) fill = values[p] < 0.0f ? -FMAX : FMAX;
+        else { values[p] = fill; set_known(p); }
+      }
     }
-  }
+  };
+  sweep(1, n1 * n1, [&](size_t l) { return l * n1; });                                          // along x
+  sweep(n1, n1 * n1, [&](size_t l) { return (l / n1) * n1 * n1 + (l % n1); });                  // along y
+  sweep(n1 * n1, n1 * n1, [&](size_t l) { return l; });                                         // along z
+  for (size_t p = 0; p < n_values; ++p)
+    if (!is_known(p)) values[p] = FMAX;   // a file without any cell
   return DISN_OK;
+}
+
+// CRC-32C (Castagnoli, reflected polynomial 0x82f63b78), slicing by 8: the checksum of the tensor-bundle
+// checkpoint format (table block trailers and BundleEntryProto.crc32c), used by disn_amd/tf_bundle.py.
+static uint32_t g_crc_tab[8][256];
+static std::atomic<int> g_crc_ready(0);
+static void crc_init() {
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82f63b78u & (0u - (c & 1u)));
+    g_crc_tab[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; ++i)
+    for (int t = 1; t < 8; ++t) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 255u];
+  g_crc_ready.store(1, std::memory_order_release);
+}
+extern "C" uint32_t disn_crc32c(uint32_t crc, const void* data, size_t n) {
+  if (!g_crc_ready.load(std::memory_order_acquire)) crc_init();   // idempotent: racing initialisers write the same table
+  const unsigned char* p = (const unsigned char*)data;
+  uint32_t c = ~crc;
+  while (n && ((uintptr_t)p & 7)) { c = (c >> 8) ^ g_crc_tab[0][(c ^ *p++) & 255u]; --n; }
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    w ^= c;
+    c = g_crc_tab[7][w & 255u] ^ g_crc_tab[6][(w >> 8) & 255u] ^ g_crc_tab[5][(w >> 16) & 255u] ^ g_crc_tab[4][(w >> 24) & 255u] ^
+        g_crc_tab[3][(w >> 32) & 255u] ^ g_crc_tab[2][(w >> 40) & 255u] ^ g_crc_tab[1][(w >> 48) & 255u] ^ g_crc_tab[0][w >> 56];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = (c >> 8) ^ g_crc_tab[0][(c ^ *p++) & 255u];
+  return ~c;
 }
 
 // integer -> decimal, returns the end pointer (faces are most of an OBJ's lines; printf is the slow part)

@@ -653,9 +653,12 @@ __global__ __launch_bounds__(BLK) void mc_triangles(const float* __restrict__ sd
 constexpr int SORT_ITEMS = 8;
 constexpr int SORT_TILE = BLK * SORT_ITEMS;
 
+// `gate` (all sort kernels): null = always run; otherwise the launch is a no-op unless *gate != 0 (the fallback
+// passes of a guarded sort are launched unconditionally -- no host round trip -- and run only when needed)
 __global__ __launch_bounds__(BLK) void tri_sort_hist(const int* __restrict__ tris, unsigned long long n, int comp, int shift,
-                                                      unsigned* __restrict__ hist, unsigned nb) {
+                                                      unsigned* __restrict__ hist, unsigned nb, const unsigned* gate) {
   __shared__ unsigned h[256];
+  if (gate && *gate == 0) return;
   h[threadIdx.x] = 0;
   __syncthreads();
   unsigned long long base = (unsigned long long)blockIdx.x * SORT_TILE;
@@ -670,8 +673,9 @@ __global__ __launch_bounds__(BLK) void tri_sort_hist(const int* __restrict__ tri
 // one workgroup per digit: exclusive scan of that digit's row hist[d][0..nb) in place,
 // row sum to total[d]; the scatter kernel adds the 256-entry digit prefix itself
 __global__ __launch_bounds__(BLK) void tri_sort_rowscan(unsigned* __restrict__ hist, unsigned nb,
-                                                         unsigned* __restrict__ total) {
+                                                         unsigned* __restrict__ total, const unsigned* gate) {
   __shared__ unsigned lds[BLK / 64];
+  if (gate && *gate == 0) return;
   unsigned* row = hist + (size_t)blockIdx.x * nb;
   unsigned carry = 0;
   for (unsigned b0 = 0; b0 < nb; b0 += BLK) {
@@ -687,10 +691,11 @@ __global__ __launch_bounds__(BLK) void tri_sort_rowscan(unsigned* __restrict__ h
 __global__ __launch_bounds__(BLK) void tri_sort_scatter(const int* __restrict__ in, int* __restrict__ out,
                                                          unsigned long long n, int comp, int shift,
                                                          const unsigned* __restrict__ hist, unsigned nb,
-                                                         const unsigned* __restrict__ total) {
+                                                         const unsigned* __restrict__ total, const unsigned* gate) {
   __shared__ unsigned basecnt[256];
   __shared__ unsigned wcnt[BLK / 64][256];
   __shared__ unsigned sl[BLK / 64];
+  if (gate && *gate == 0) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   {
     unsigned tot;   // digit prefix over the 256 row totals, then this block's offset inside the row
@@ -741,26 +746,43 @@ __global__ __launch_bounds__(BLK) void tri_sort_scatter(const int* __restrict__ 
 // After the stable sort on the first index: triangles with equal first index form short runs (a vertex is the
 // smallest index of at most its valence many triangles).  Each thread finds its run and its rank inside it by
 // (second, third, position) and writes the triple to its final place: the result is the full lexicographic order
-// with a third of the radix passes.  Work is the sum of squared run lengths -- fine for meshes, and still correct
-// (only slow) for inputs with long runs.
-__global__ __launch_bounds__(BLK) void tri_sort_ties(const int* __restrict__ in, int* __restrict__ out, unsigned long long n) {
+// with a third of the radix passes.  Work is the sum of squared run lengths -- fine for meshes.  GUARD (the public
+// sort entry points, whose input is arbitrary): a thread that has to look further than TIES_MAX_LOOK triples in
+// either direction raises *flag and writes nothing; the caller's gated radix passes on the other two components
+// then produce the result instead, so the work stays O(n) for any input.
+constexpr unsigned TIES_MAX_LOOK = 64;
+template <bool GUARD>
+__global__ __launch_bounds__(BLK) void tri_sort_ties(const int* __restrict__ in, int* __restrict__ out, unsigned long long n,
+                                                      unsigned* flag) {
   const unsigned long long t = (unsigned long long)blockIdx.x * BLK + threadIdx.x;
   if (t >= n) return;
   const int a = in[3 * t], b = in[3 * t + 1], c = in[3 * t + 2];
   unsigned long long lo = t, hi = t + 1;
-  unsigned rank = 0;
+  unsigned rank = 0, look = 0;
   while (lo > 0 && in[3 * (lo - 1)] == a) {
+    if (GUARD && ++look > TIES_MAX_LOOK) { *flag = 1u; return; }
     --lo;
     const int b2 = in[3 * lo + 1], c2 = in[3 * lo + 2];
     rank += (b2 < b) || (b2 == b && c2 <= c);          // equal triples keep their order (stable)
   }
+  look = 0;
   while (hi < n && in[3 * hi] == a) {
+    if (GUARD && ++look > TIES_MAX_LOOK) { *flag = 1u; return; }
     const int b2 = in[3 * hi + 1], c2 = in[3 * hi + 2];
     rank += (b2 < b) || (b2 == b && c2 < c);
     ++hi;
   }
   int* o = out + 3 * (lo + rank);
   o[0] = a; o[1] = b; o[2] = c;
+}
+
+// dst = src when (*gate != 0) == want
+__global__ void tri_copy_gated(const int* __restrict__ src, int* __restrict__ dst, unsigned long long n3, const unsigned* gate,
+                               int want) {
+  if ((*gate != 0) != (want != 0)) return;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n3;
+       i += (unsigned long long)gridDim.x * blockDim.x)
+    dst[i] = src[i];
 }
 
 }  // namespace
@@ -845,36 +867,57 @@ extern "C" int disn_mc_count(DisnCtx* ctx, const float* sdf, const DisnMcGrid* g
   return DISN_OK;
 }
 
-// the sort proper on caller-chosen scratch: tmp = n*3 ints, hist = (nb*256 + 256) unsigned.  Every scratch word
-// that is read has been written earlier in the same pass, so neither buffer needs to start at zero.
+// the sort proper on caller-chosen scratch: tmp = n*3 ints, hist = (nb*256 + 256 + 1) unsigned.  Every scratch word
+// that is read has been written earlier in the same call, so neither buffer needs to start at zero.
+// guard = false: marching-cubes output (runs of equal first index are bounded by the vertex valence);
+// guard = true: arbitrary triangle lists (see tri_sort_ties).
+constexpr size_t sort_hist_words(unsigned nb) { return (size_t)nb * 256 + 256 + 1; }
 static int sort_tris_on(DisnCtx* ctx, int* tris, uint64_t n, uint64_t max_index, int* tmp, unsigned* hist,
-                        hipStream_t stream) {
+                        hipStream_t stream, bool guard) {
   if (n < 2) return DISN_OK;
   int bits = 1;
   while (bits < 32 && (max_index >> bits)) ++bits;
   const int passes = (bits + 7) / 8;
   const unsigned nb = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+  unsigned* total = hist + (size_t)nb * 256;
+  unsigned* flag = total + 256;
   int* a = tris;
   int* b = tmp;
-  for (int ps = 0; ps < passes; ++ps) {   // stable LSD radix sort on the first index only ...
-    tri_sort_hist<<<nb, BLK, 0, stream>>>(a, n, 0, 8 * ps, hist, nb);
-    tri_sort_rowscan<<<256, BLK, 0, stream>>>(hist, nb, hist + (size_t)nb * 256);
-    tri_sort_scatter<<<nb, BLK, 0, stream>>>(a, b, n, 0, 8 * ps, hist, nb, hist + (size_t)nb * 256);
-    int* t = a; a = b; b = t;
+  auto radix = [&](int comp, const unsigned* gate) {
+    for (int ps = 0; ps < passes; ++ps) {
+      tri_sort_hist<<<nb, BLK, 0, stream>>>(a, n, comp, 8 * ps, hist, nb, gate);
+      tri_sort_rowscan<<<256, BLK, 0, stream>>>(hist, nb, total, gate);
+      tri_sort_scatter<<<nb, BLK, 0, stream>>>(a, b, n, comp, 8 * ps, hist, nb, total, gate);
+      int* t = a; a = b; b = t;
+    }
+  };
+  const unsigned tb = (unsigned)((n + BLK - 1) / BLK);
+  radix(0, nullptr);   // stable LSD radix sort on the first index only ...
+  if (!guard) {
+    tri_sort_ties<false><<<tb, BLK, 0, stream>>>(a, b, n, nullptr);   // ... then order the short runs
+    if (b != tris) DISN_HIP(ctx, hipMemcpyAsync(tris, b, n * 3 * sizeof(int), hipMemcpyDeviceToDevice, stream));
+    DISN_HIP(ctx, hipGetLastError());
+    return DISN_OK;
   }
-  tri_sort_ties<<<(unsigned)((n + BLK - 1) / BLK), BLK, 0, stream>>>(a, b, n);   // ... then order the short runs
-  { int* t = a; a = b; b = t; }
-  if (a != tris) DISN_HIP(ctx, hipMemcpyAsync(tris, a, n * 3 * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  DISN_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), stream));
+  tri_sort_ties<true><<<tb, BLK, 0, stream>>>(a, b, n, flag);
+  int* short_runs = b;   // the result when no long run was met
+  radix(2, flag);        // otherwise: the remaining passes of a full LSD sort, third index, second, first again
+  radix(1, flag);
+  radix(0, flag);
+  const unsigned cb = tb < 4096 ? tb : 4096;
+  if (short_runs != tris) tri_copy_gated<<<cb, BLK, 0, stream>>>(short_runs, tris, n * 3, flag, 0);
+  if (a != tris) tri_copy_gated<<<cb, BLK, 0, stream>>>(a, tris, n * 3, flag, 1);
   DISN_HIP(ctx, hipGetLastError());
   return DISN_OK;
 }
 
-static int sort_tris(DisnCtx* ctx, McState* m, int* tris, uint64_t n, uint64_t max_index, hipStream_t stream) {
+static int sort_tris(DisnCtx* ctx, McState* m, int* tris, uint64_t n, uint64_t max_index, hipStream_t stream, bool guard) {
   if (n < 2) return DISN_OK;
   const unsigned nb = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
   DISN_TRY(disn_ensure(ctx, m->sort_tmp, n * 3 * sizeof(int)));
-  DISN_TRY(disn_ensure(ctx, m->sort_hist, ((size_t)nb * 256 + 256) * sizeof(unsigned)));
-  return sort_tris_on(ctx, tris, n, max_index, (int*)m->sort_tmp.p, (unsigned*)m->sort_hist.p, stream);
+  DISN_TRY(disn_ensure(ctx, m->sort_hist, sort_hist_words(nb) * sizeof(unsigned)));
+  return sort_tris_on(ctx, tris, n, max_index, (int*)m->sort_tmp.p, (unsigned*)m->sort_hist.p, stream, guard);
 }
 
 // ---- allocation-free triangle sort (disn_sort_triangles_static) ------------
@@ -887,7 +930,7 @@ static int sort_tris(DisnCtx* ctx, McState* m, int* tris, uint64_t n, uint64_t m
 constexpr uint64_t SORT_STATIC_MAX_TRIS = 1ull << 20;                                  // 1 Mi triangles
 constexpr unsigned SORT_STATIC_MAX_NB = (unsigned)(SORT_STATIC_MAX_TRIS / SORT_TILE);   // 512 sort tiles
 constexpr size_t SORT_STATIC_TMP_BYTES = SORT_STATIC_MAX_TRIS * 3 * sizeof(int);        // 12 MiB
-constexpr size_t SORT_STATIC_HIST_BYTES = ((size_t)SORT_STATIC_MAX_NB * 256 + 256) * sizeof(unsigned);
+constexpr size_t SORT_STATIC_HIST_BYTES = sort_hist_words(SORT_STATIC_MAX_NB) * sizeof(unsigned);
 static __device__ __align__(256) unsigned char scratch[SORT_STATIC_TMP_BYTES + SORT_STATIC_HIST_BYTES];
 
 constexpr int MAX_DEVICES = 64;
@@ -921,7 +964,8 @@ extern "C" int disn_sort_triangles_static(DisnCtx* ctx, int32_t* tris, uint64_t 
   if (!ctx->static_scratch) return disn_fail(ctx, DISN_E_STATE, "disn_sort_triangles_static: static scratch not initialised");
   DISN_HIP(ctx, hipSetDevice(ctx->device));
   unsigned char* base = (unsigned char*)ctx->static_scratch;   // the device pointer, never the symbol
-  return sort_tris_on(ctx, tris, n, max_index, (int*)base, (unsigned*)(base + SORT_STATIC_TMP_BYTES), (hipStream_t)stream_);
+  return sort_tris_on(ctx, tris, n, max_index, (int*)base, (unsigned*)(base + SORT_STATIC_TMP_BYTES), (hipStream_t)stream_,
+                      true);
 }
 
 extern "C" int disn_mc_emit(DisnCtx* ctx, const double* bbox, uint64_t centre_base, uint64_t edge_base, double* verts,
@@ -957,7 +1001,7 @@ extern "C" int disn_mc_emit(DisnCtx* ctx, const double* bbox, uint64_t centre_ba
                                           (const unsigned*)m->coff.p, (const unsigned*)m->vbase.p,
                                           (const unsigned*)m->layer_asc.p, a);
   DISN_HIP(ctx, hipGetLastError());
-  if (sort) DISN_TRY(sort_tris(ctx, m, tris, nt, max_index, stream));
+  if (sort) DISN_TRY(sort_tris(ctx, m, tris, nt, max_index, stream, false));
   return DISN_OK;
 }
 
@@ -977,5 +1021,5 @@ extern "C" int disn_sort_triangles(DisnCtx* ctx, int32_t* tris, uint64_t n, uint
   if (n && !tris) return disn_fail(ctx, DISN_E_ARG, "disn_sort_triangles: null buffer");
   if (max_index >= (1ull << 31)) return disn_fail(ctx, DISN_E_ARG, "disn_sort_triangles: indices exceed int32");
   DISN_HIP(ctx, hipSetDevice(ctx->device));
-  return sort_tris(ctx, mc_state(ctx), tris, n, max_index, (hipStream_t)stream_);
+  return sort_tris(ctx, mc_state(ctx), tris, n, max_index, (hipStream_t)stream_, true);
 }

@@ -1507,6 +1507,8 @@ struct SdfState {
   int num_cu = 256;
   int decoder = DISN_DECODER_MIXED;
   bool have_weights = false, have_image = false, lds_attr_set = false, lds_attr_set_mx = false;
+  bool mixed_ok = false;      // the mixed stream could be packed (all MFMA-layer weights inside the fp16 range)
+  float mixed_bad_max = 0;    // ... else the offending max |w|
 };
 
 void disn_sdf_state_free(DisnCtx* ctx) {
@@ -1617,12 +1619,17 @@ static void pack_group(std::vector<uint8_t>& out, const float* W, int N, int nb,
     }
   }
 }
-// scale exponents of one layer: rows 0..K-1 of W[.][N]
+// scale exponents of one layer: rows 0..K-1 of W[.][N] (finite: checked by disn_sdf_set_weights)
 static void layer_scale(const float* W, int K, int N, int* a_w, float* maxabs) {
   float mw = 0.0f;
   for (size_t i = 0; i < (size_t)K * N; ++i) mw = fmaxf(mw, fabsf(W[i]));
   *a_w = fp8_scale_exp(mw);
   *maxabs = mw;
+}
+static bool all_finite(const float* p, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if (!(p[i] - p[i] == 0.0f)) return false;   // NaN and +-inf both fail
+  return true;
 }
 
 static int upload(DisnCtx* ctx, DevBuf& b, const void* src, size_t bytes) {
@@ -1639,12 +1646,23 @@ extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
     if (!ptrs[i]) return disn_fail(ctx, DISN_E_ARG, "disn_sdf_set_weights: weight pointer %zu is null", i);
   DISN_HIP(ctx, hipSetDevice(ctx->device));
   SdfState* s = sdf_state(ctx);
+  s->have_weights = false;   // a failure below must not leave a half-packed set usable
+  s->have_image = false;
+  s->mixed_ok = true;
   struct Stream { const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4, *w5, *b5, *w6, *b6; };
   const Stream st[2] = {
       {w->g_f1c1_w, w->g_f1c1_b, w->g_f1c2_w, w->g_f1c2_b, w->g_f1c3_w, w->g_f1c3_b, w->g_f2c1_w, w->g_f2c1_b,
        w->g_f2c2_w, w->g_f2c2_b, w->g_f2c5_w, w->g_f2c5_b},
       {w->l_f1c1_w, w->l_f1c1_b, w->l_f1c2_w, w->l_f1c2_b, w->l_f1c3_w, w->l_f1c3_b, w->l_f2c1_w, w->l_f2c1_b,
        w->l_f2c2_w, w->l_f2c2_b, w->l_f2c5_w, w->l_f2c5_b}};
+  for (int t = 0; t < 2; ++t) {
+    const Stream& q = st[t];
+    const float* arr[12] = {q.w1, q.b1, q.w2, q.b2, q.w3, q.b3, q.w4, q.b4, q.w5, q.b5, q.w6, q.b6};
+    const size_t cnt[12] = {3 * 64, 64, 64 * 256, 256, 256 * 512, 512, (size_t)(t ? 1984 : 1536) * 512, 512, 512 * 256, 256, 256, 1};
+    for (int i = 0; i < 12; ++i)
+      if (!all_finite(arr[i], cnt[i]))
+        return disn_fail(ctx, DISN_E_ARG, "disn_sdf_set_weights: %s stream, array %d holds a non-finite value", t ? "local" : "global", i);
+  }
   for (int t = 0; t < 2; ++t) {
     const Stream& q = st[t];
     std::vector<uint16_t> frag;
@@ -1675,10 +1693,13 @@ extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
       for (int l = 0; l < 3; ++l) {
         float mx;
         layer_scale(lw[l], lk[l], ln[l], &sc_exp[l], &mx);
-        if (!(mx < 65504.0f))
-          return disn_fail(ctx, DISN_E_ARG, "disn_sdf_set_weights: stream %d layer %d holds a non-finite weight or one beyond "
-                           "the fp16 range (max |w| = %g)", t, l, (double)mx);
+        if (!(mx < 65504.0f)) {   // beyond fp16: only the bf16x3 decoder can run these weights
+          s->mixed_ok = false;
+          s->mixed_bad_max = mx;
+        }
       }
+    }
+    if (s->mixed_ok) {
       std::vector<uint8_t> mxs;
       mxs.reserve((size_t)PAIRS * 2048);
       for (int nb2 = 0; nb2 < 8; ++nb2) pack_group(mxs, q.w2, 256, nb2, 0, sc_exp[0]);
@@ -1790,6 +1811,9 @@ static int launch_decode(DisnCtx* ctx, DecodeArgs& a, const float* trans_mat, hi
   if (tiles * STAGES_PER_TILE > 0x7fffffffll) return disn_fail(ctx, DISN_E_ARG, "too many points for one launch");
   const unsigned blocks = (unsigned)(tiles < s->num_cu ? tiles : s->num_cu);
   if (s->decoder == DISN_DECODER_MIXED) {
+    if (!s->mixed_ok)
+      return disn_fail(ctx, DISN_E_STATE, "the loaded weights reach |w| = %g, beyond the fp16 range of the mixed decoder: "
+                       "select DISN_DECODER_BF16X3 (disn_sdf_set_decoder)", (double)s->mixed_bad_max);
     if (!s->lds_attr_set_mx) {
       DISN_HIP(ctx, hipFuncSetAttribute((const void*)sdf_decode_mx<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));
       DISN_HIP(ctx, hipFuncSetAttribute((const void*)sdf_decode_mx<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));

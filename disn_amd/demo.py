@@ -21,6 +21,19 @@ import numpy as np
 import torch
 
 
+DEMO_IMAGE = "03001627_17e916fc863540ee3def89b32cef8e45_20.png"     # reference demo/demo.py:262
+
+
+def default_image():
+    """The image the reference's demo meshes when none is given (demo/demo.py:262): ./demo/<name> relative to the
+    working directory like the reference, else this repository's data copy of it; None if neither exists."""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join("demo", DEMO_IMAGE), os.path.join(here, "tests", "golden", "demo_chair_20.png")):
+        if os.path.exists(p):
+            return p
+    return None
+
+
 def read_image(path):
     """(137,137,3) float32 in [0,1], BGR channel order like cv2.imread (reference demo/demo.py:263-264)."""
     from PIL import Image
@@ -47,7 +60,9 @@ def main(argv=None):
                     help="run on seeded random-init weights instead of checkpoints (no checkpoint is otherwise an error)")
     ap.add_argument("--img_h", type=int, default=137)
     ap.add_argument("--img_w", type=int, default=137)
-    ap.add_argument("--image", default=None, help="137x137 PNG (default: seeded synthetic view)")
+    ap.add_argument("--image", default=None,
+                    help="137x137 PNG (default: the reference's demo chair, demo/demo.py:262, looked up as "
+                         "./demo/%s or the copy under tests/golden/; a seeded synthetic view if neither exists)" % DEMO_IMAGE)
     ap.add_argument("--out", default="demo/result.obj")
     ap.add_argument("--seed", type=int, default=0)
     FLAGS = ap.parse_args(argv)
@@ -84,7 +99,13 @@ def main(argv=None):
         log("Model loading from %s" % ckpt)
         ctx.set_weights(tf_bundle.decoder_weights(ckpt))
         enc = Vgg16Encoder(ctx, tf_bundle.vgg_weights(ckpt))
-    img = read_image(FLAGS.image) if FLAGS.image else synth.image(FLAGS.seed)
+    img_path = FLAGS.image or default_image()
+    if img_path:
+        log("demo: image %s" % img_path)
+        img = read_image(img_path)
+    else:
+        log("demo: no --image and the demo chair is not around: seeded synthetic view (seed %d)" % FLAGS.seed)
+        img = synth.image(FLAGS.seed)
     if FLAGS.cam_est:
         # reference demo/demo.py:195-258: a second VGG-16 (own weights) + the pose heads
         from . import camera
@@ -100,7 +121,11 @@ def main(argv=None):
             log("Model loading from %s" % cam_ckpt)
             cam_vgg, cam_w = tf_bundle.vgg_weights(cam_ckpt), tf_bundle.camera_weights(cam_ckpt)
         cam_emb, _ = Vgg16Encoder(ctx, cam_vgg, slot=1)(img, feats=False)
-        trans_mat = camera.pred_trans_mat(cam_emb, cam_w)[0].cpu().numpy()
+        tm_t = camera.pred_trans_mat(cam_emb, cam_w)[0].contiguous()
+        if world > 1:                                  # one matrix for all ranks: slab seams need identical projections
+            from .pipeline import _Comm
+            _Comm(dist).broadcast(tm_t, src=0)
+        trans_mat = tm_t.cpu().numpy()
         log("pred_trans_mat_val", trans_mat)
     else:
         log("here we use gt cam parameters")
@@ -118,7 +143,10 @@ def main(argv=None):
         # every rank holds the same features after this broadcast, so every rank computes the same number
         feats, gfeat = pipe._broadcast_features(feats, gfeat)
         ctx.set_image(feats, gfeat)
-        iso = coarse_median_iso(ctx, trans_mat, sdf_params)
+        iso_t = torch.tensor([coarse_median_iso(ctx, trans_mat, sdf_params)], dtype=torch.float32, device=ctx.device)
+        if world > 1:                                  # rank 0's value for everyone: counts and vertex bases must agree
+            pipe.dist.broadcast(iso_t, src=0)
+        iso = float(iso_t.item())
         log("demo: --random_init without --iso: using the median of a coarse whole-box grid, %.9g "
             "(random weights have no zero level set)" % iso)
     torch.cuda.synchronize()

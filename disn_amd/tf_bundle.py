@@ -7,16 +7,23 @@ tensors out of `<prefix>.data-00000-of-0000N`.  Only what the released DISN
 checkpoints need: uncompressed table blocks, DT_FLOAT / DT_INT32 / DT_INT64
 tensors, unsliced entries.
 
+Every table block's trailer checksum and every tensor's BundleEntryProto.crc32c
+(masked CRC-32C, as TensorFlow writes them) are verified: a truncated or
+corrupted checkpoint is an error, never a silently different mesh.
+
 PARITY UNPINNED: the released checkpoints are not in the reference tree
 (README.md:39-50 fetches them), so this reader is exercised against bundles
 written by tests/tf_bundle_writer.py, which follows the same published format
 (tensorflow/core/util/tensor_bundle, tensorflow/core/lib/io/table).
 """
+import ctypes
 import os
 import re
 import struct
 
 import numpy as np
+
+from . import _lib
 
 TABLE_MAGIC = 0xdb4775248b80fb57
 DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64}
@@ -54,10 +61,24 @@ def _block_entries(block):
         pos += vlen
 
 
+def crc32c(data, crc=0):
+    """CRC-32C of a bytes-like object or a contiguous uint8 array (libdisn_hip.so's host helper)."""
+    a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8)
+    return int(_lib.load().disn_crc32c(crc, a.ctypes.data_as(ctypes.c_void_p), a.size))
+
+
+def crc_mask(crc):
+    """tensorflow/core/lib/hash/crc32c.h Mask(): rotate right by 15 and add a constant."""
+    return (((crc >> 15) | (crc << 17)) + 0xa282ead8) & 0xffffffff
+
+
 def _read_block(blob, offset, size):
     if offset + size + 5 > len(blob):
-        raise BundleError("block handle outside the file")
+        raise BundleError("block handle outside the file (truncated index?)")
     ctype = blob[offset + size]
+    stored = struct.unpack_from("<I", blob, offset + size + 1)[0]
+    if crc_mask(crc32c(blob[offset:offset + size + 1])) != stored:
+        raise BundleError("table block at offset %d fails its checksum (corrupt index file)" % offset)
     if ctype != 0:
         raise BundleError("compressed table blocks (type %d) are not supported" % ctype)
     return blob[offset:offset + size]
@@ -127,7 +148,8 @@ def read_index(prefix):
             if dt not in DTYPES:
                 raise BundleError("tensor %r has unsupported dtype enum %d" % (key.decode(), dt))
             entries[key.decode()] = dict(dtype=DTYPES[dt], shape=_shape(m[2][0]) if 2 in m else (),
-                                         shard=m.get(3, [0])[0], offset=m.get(4, [0])[0], size=m.get(5, [0])[0])
+                                         shard=m.get(3, [0])[0], offset=m.get(4, [0])[0], size=m.get(5, [0])[0],
+                                         crc32c=m.get(6, [None])[0])
     return shards, entries
 
 
@@ -153,8 +175,12 @@ def read_bundle(prefix, names=None):
         count = int(np.prod(e["shape"], dtype=np.int64))
         if count * np.dtype(e["dtype"]).itemsize != e["size"] or e["offset"] + e["size"] > files[path].shape[0]:
             raise BundleError("tensor %r: size/offset do not match its shape" % n)
-        raw = files[path][e["offset"]:e["offset"] + e["size"]]
-        out[n] = np.frombuffer(raw.tobytes(), dtype=e["dtype"]).reshape(e["shape"]).copy()
+        raw = np.array(files[path][e["offset"]:e["offset"] + e["size"]])      # one copy out of the map
+        if e["crc32c"] is None:
+            raise BundleError("tensor %r carries no checksum" % n)
+        if crc_mask(crc32c(raw)) != e["crc32c"]:
+            raise BundleError("tensor %r fails its checksum (corrupt or truncated data file %s)" % (n, path))
+        out[n] = raw.view(e["dtype"]).reshape(e["shape"])
     return out
 
 

@@ -209,14 +209,23 @@ int disn_read_dist_header(const char* path, int* res, double* bbox);
 int disn_read_dist(const char* path, float* values, size_t n_values);
 /* Narrow-band .n.dist reader (the `-n` input mode of the reference tool; format of the shipped
  * fixture isosurface/model_normalized.obj.n.dist): dense header, int32 N,
- * N x (int32 i, j, k, float32 d).  disn_read_ndist expands it to a dense (res+1)^3 grid, x fastest,
- * cells outside the band = +FLT_MAX (exterior).  HOST pointers. */
+ * N x (int32 i, j, k, float32 d).  disn_read_ndist expands it to a dense (res+1)^3 grid, x fastest.
+ * Cells outside the band read +FLT_MAX (exterior) or -FLT_MAX (interior); the file has no flag for the
+ * side, so it is inferred from the band: a missing cell takes the sign (relative to 0, i.e. the band is
+ * assumed closed and meshed at iso ~ 0) of the last listed cell passed along +x, cells in front of a
+ * line's first listed cell take that cell's sign, lines without listed cells are resolved along y, then z.
+ * HOST pointers. */
 int disn_read_ndist_header(const char* path, int* res, double* bbox, int64_t* n_cells);
 int disn_read_ndist(const char* path, float* values, size_t n_values);
 /* OBJ writer in the reference tool's text format:
  * header comments, `v x y z` with 6 significant digits, `f a b c` 1-based. */
 int disn_write_obj(const char* path, const double* verts, uint64_t n_verts, const int32_t* tris,
                    uint64_t n_tris);
+
+/* CRC-32C (Castagnoli) of n bytes continuing from `crc` (0 to start): the checksum of the TensorFlow
+ * tensor-bundle checkpoint format that replaces Saver.restore's own verification (reference
+ * demo/demo.py:153-165); used by the checkpoint reader disn_amd/tf_bundle.py.  HOST pointer. */
+uint32_t disn_crc32c(uint32_t crc, const void* data, size_t n);
 
 #ifdef __cplusplus
 }

@@ -116,3 +116,35 @@ def test_narrowband_missing_cells_take_the_sign_of_their_side(tmp_path):
     assert bool((grid[~band & (full > 0)] == np.finfo(np.float32).max).all())
     a, b = mc.marching_cubes(grid, iso=0.0), mc.marching_cubes(full, iso=0.0)
     assert a["n_tri"] > 500 and np.array_equal(a["tris"], b["tris"]) and np.array_equal(a["verts"], b["verts"])
+
+
+def test_narrowband_band_open_at_the_box_wall(tmp_path):
+    """A surface that leaves the box: a sphere centred on the x = -1 wall, so grid lines through it START inside the
+    surface, plus a slab through the whole box whose interior lines hold no band cell at all (resolved along y / z).
+    Every missing cell must take the sign of its side and the band grid must mesh like the full field."""
+    import struct
+    from disn_amd import api
+    res = 24
+    l = np.linspace(-1, 1, res + 1)
+    z, y, x = np.meshgrid(l, l, l, indexing="ij")
+    sphere = np.sqrt((x + 1.0) ** 2 + y ** 2 + z ** 2) - 0.55          # cut open by the wall x = -1
+    slab = np.abs(z - 0.6) - 0.22                                      # spans the box in x and y: interior rows list nothing
+    full = np.minimum(sphere, slab).astype(np.float32)
+    band = np.abs(full) < 1.6 * (2.0 / res)
+    k, j, i = np.nonzero(band)
+    p = str(tmp_path / "open.n.dist")
+    with open(p, "wb") as f:
+        f.write(struct.pack("<3i", -res, res, res) + struct.pack("<6d", -1, -1, -1, 1, 1, 1) + struct.pack("<i", len(i)))
+        rec = np.zeros(len(i), dtype=np.dtype([("i", "<i4"), ("j", "<i4"), ("k", "<i4"), ("d", "<f4")]))
+        rec["i"], rec["j"], rec["k"], rec["d"] = i, j, k, full[band]
+        f.write(rec.tobytes())
+    r, bbox, grid, n = api.read_narrowband_dist(p)
+    assert r == res and n == len(i) and np.array_equal(grid[band], full[band])
+    inside, outside = ~band & (full < 0), ~band & (full > 0)
+    assert int(inside[:, :, 0].sum()) > 20                             # rows that begin inside the sphere at the wall
+    rows_without_cells = ~band.any(axis=2)
+    assert int((rows_without_cells & (full[:, :, 0] < 0)).sum()) > 20  # interior rows of the slab
+    assert bool((grid[inside] == -np.finfo(np.float32).max).all())
+    assert bool((grid[outside] == np.finfo(np.float32).max).all())
+    a, b = mc.marching_cubes(grid, iso=0.0), mc.marching_cubes(full, iso=0.0)
+    assert a["n_tri"] > 500 and np.array_equal(a["tris"], b["tris"]) and np.array_equal(a["verts"], b["verts"])

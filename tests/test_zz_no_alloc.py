@@ -48,3 +48,33 @@ def test_static_sort_full_size_and_limit(ctx):
     t = _tris(1000, 999, 6)
     a, b = _both(ctx, t, 999)
     assert np.array_equal(a, b)
+
+
+def test_sort_with_long_runs_of_equal_first_index(ctx):
+    """The public sort entry points take arbitrary triangle lists: a fan of 300 000 triangles around one smallest
+    vertex, an all-equal first column, and runs just below / above the look-ahead bound of the run-ordering kernel
+    (the long-run inputs take the gated full radix passes instead) -- both entry points against np.lexsort."""
+    rng = np.random.default_rng(11)
+    cases = []
+    fan = rng.integers(1, 50_000, size=(300_000, 3)).astype(np.int32)
+    fan[:, 0] = 0
+    cases.append((fan, 50_000))
+    allsame = rng.integers(0, 1 << 20, size=(70_001, 3)).astype(np.int32)
+    allsame[:, 0] = 777
+    cases.append((allsame, 1 << 20))
+    for run in (63, 64, 65, 66, 130):                 # runs around TIES_MAX_LOOK = 64
+        t = rng.integers(0, 3000, size=(20_000, 3)).astype(np.int32)
+        t[5000:5000 + run, 0] = 1234
+        cases.append((t, 3000))
+    mixed = _tris(100_000, 900, 12)                   # ~111 triangles per first index on average
+    cases.append((mixed, 900))
+    for t, max_index in cases:
+        a, b = _both(ctx, t, max_index)
+        want = t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
+        assert np.array_equal(a, want), (len(t), max_index)
+        assert np.array_equal(b, want), (len(t), max_index)
+    # a short-run input right after a long-run one: the flag of the previous call must not leak
+    t = _tris(10_000, 70_000, 13)
+    a, b = _both(ctx, t, 70_000)
+    want = t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
+    assert np.array_equal(a, want) and np.array_equal(b, want)
