@@ -35,6 +35,9 @@ SIGNATURES = {
     "disn_version": (c_char_p, []),
     "disn_sdf_set_weights": (c_int, [c_void_p, ctypes.POINTER(DisnDecoderWeights)]),
     "disn_sdf_set_decoder": (c_int, [c_void_p, c_int]),
+    "disn_sdf_selfcheck": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
+    "disn_sdf_autotune": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, ctypes.POINTER(c_int),
+                                  ctypes.POINTER(c_float), c_void_p]),
     "disn_sdf_set_image": (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
     "disn_sdf_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "disn_sdf_points": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

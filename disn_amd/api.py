@@ -49,6 +49,10 @@ class Context:
             raise DisnError("disn_create(%s) failed with %d" % (self.device, rc))
         self._h = h
         self._mc_counts = None
+        self.auto_decoder = True       # decoder arithmetic chosen by measurement at the first evaluation after set_weights
+        self._tuned = False
+        self.decoder = "mixed"         # what the library runs right now (its own default until tuned / set)
+        self.decoder_report = None     # last autotune: {"chosen", "errors", "tolerance", "margin"}
 
     def close(self):
         if getattr(self, "_h", None):
@@ -79,14 +83,55 @@ class Context:
                     keep.append(a)
                     setattr(st, name, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
         self._check(self.lib.disn_sdf_set_weights(self._h, ctypes.byref(st)), "disn_sdf_set_weights")
+        self._tuned = False            # new weights: the arithmetic is measured again
 
-    DECODERS = {"mixed": 0, "bf16x3": 1}
+    DECODERS = {"mixed": 0, "bf16x3": 1, "mixed4": 2}
+    DECODER_NAMES = {v: k for k, v in DECODERS.items()}
+    TOLERANCE = 1e-4                   # BASELINE.json north_star: SDF within 1e-4 absolute
+    MARGIN = 5.0                       # the chosen arithmetic keeps 5x to it on the sample points
 
     def set_decoder(self, name):
-        """'mixed' (default: fp16 + fp8 residual products, bf16x3 last layer) or 'bf16x3' (every layer)."""
+        """'auto' (default): at the first evaluation after set_weights the library measures, on 4096 points of the
+        box being evaluated, the error of each arithmetic against the as-written fp32 graph and takes the cheapest
+        one that keeps MARGIN x to TOLERANCE: 'mixed4' (fp16 + 2 fp8 residual products in all four MFMA layers),
+        'mixed' (the same on three layers, bf16x3 on fold2/conv2) or 'bf16x3' (every layer).  A name pins one."""
+        if name == "auto":
+            self.auto_decoder, self._tuned = True, False
+            return
         if name not in self.DECODERS:
-            raise DisnError("set_decoder: unknown decoder %r (have %s)" % (name, sorted(self.DECODERS)))
+            raise DisnError("set_decoder: unknown decoder %r (have auto, %s)" % (name, ", ".join(sorted(self.DECODERS))))
         self._check(self.lib.disn_sdf_set_decoder(self._h, self.DECODERS[name]), "disn_sdf_set_decoder")
+        self.auto_decoder, self.decoder = False, name
+
+    def selfcheck(self, trans_mat, sdf_params=(-1, -1, -1, 1, 1, 1), n=4096):
+        """(max |decoder - as-written fp32 graph|, max |SDF|) over n sample points of the box (disn_sdf_selfcheck)."""
+        tm = np.ascontiguousarray(np.asarray(trans_mat, dtype=np.float32).reshape(12))
+        sp = np.ascontiguousarray(np.asarray(sdf_params, dtype=np.float64).reshape(6))
+        err, mx = ctypes.c_float(), ctypes.c_float()
+        self._check(self.lib.disn_sdf_selfcheck(self._h, tm.ctypes.data, sp.ctypes.data, n, ctypes.byref(err),
+                                                ctypes.byref(mx), _stream()), "disn_sdf_selfcheck")
+        return float(err.value), float(mx.value)
+
+    def autotune(self, trans_mat, sdf_params=(-1, -1, -1, 1, 1, 1), n=4096, tolerance=None, margin=None):
+        """Pick the decoder arithmetic by measurement (disn_sdf_autotune); raises if none keeps the margin."""
+        tm = np.ascontiguousarray(np.asarray(trans_mat, dtype=np.float32).reshape(12))
+        sp = np.ascontiguousarray(np.asarray(sdf_params, dtype=np.float64).reshape(6))
+        tol = self.TOLERANCE if tolerance is None else tolerance
+        mg = self.MARGIN if margin is None else margin
+        chosen, errs = ctypes.c_int(-1), (ctypes.c_float * 3)()
+        rc = self.lib.disn_sdf_autotune(self._h, tm.ctypes.data, sp.ctypes.data, n, tol, mg, ctypes.byref(chosen), errs,
+                                        _stream())
+        if chosen.value >= 0:
+            self.decoder = self.DECODER_NAMES[chosen.value]
+        self.decoder_report = {"chosen": self.decoder, "tolerance": tol, "margin": mg, "points": n,
+                               "errors": {self.DECODER_NAMES[i]: (float(errs[i]) if errs[i] >= 0 else None) for i in range(3)}}
+        self._check(rc, "disn_sdf_autotune")
+        self._tuned = True
+        return self.decoder_report
+
+    def _auto(self, trans_mat, sdf_params):
+        if self.auto_decoder and not self._tuned:
+            self.autotune(trans_mat, sdf_params)
 
     def set_image(self, feat_maps, global_feat):
         """feat_maps: five NHWC/HWC float32 end points (conv1_2..conv5_3); global_feat: [1024]."""
@@ -112,6 +157,7 @@ class Context:
         z1 = res if z1 is None else z1
         tm = np.ascontiguousarray(np.asarray(trans_mat, dtype=np.float32).reshape(12))
         sp = np.ascontiguousarray(np.asarray(sdf_params, dtype=np.float64).reshape(6))
+        self._auto(tm, sp)
         shape = (z1 - z0 + 1, res + 1, res + 1)
         if out is None:
             out = torch.empty(shape, dtype=torch.float32, device=self.device)
@@ -128,6 +174,7 @@ class Context:
         pr = p if pts_rot is None else _dev_f32(pts_rot, self.device).reshape(-1, 3)
         if pr.shape != p.shape:
             raise DisnError("sdf_points: pts and pts_rot differ in shape")
+        self._auto(tm, (-1, -1, -1, 1, 1, 1))
         out = torch.empty(p.shape[0], dtype=torch.float32, device=self.device)
         self._check(self.lib.disn_sdf_points(self._h, tm.ctypes.data, p.data_ptr(), pr.data_ptr(), p.shape[0],
                                              out.data_ptr(), _stream()), "disn_sdf_points")

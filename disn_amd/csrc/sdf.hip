@@ -49,7 +49,7 @@ constexpr int SP_B3 = 512;    // [512]
 constexpr int SP_B5 = 1024;   // [256]
 constexpr int SP_W6 = 1280;   // [256]
 constexpr int SP_B6 = 1536;   // [1]
-constexpr int SP_SC = 1540;   // [3] (ints) E8M0 scale byte of the fp8 weight operands of fold1/conv2, fold1/conv3, fold2/conv1
+constexpr int SP_SC = 1540;   // [4] (ints) E8M0 scale byte of the fp8 weight operands of fold1/conv2, fold1/conv3, fold2/conv1, fold2/conv2
 constexpr int SP_MX_LDS = 1544;   // the mixed-precision kernel keeps [0, SP_MX_LDS) in LDS and reads B4 from global memory
 constexpr int SP_B4 = 1544;   // [512] (global stream: includes the hoisted global-feature term)
 constexpr int SP_SIZE = 2056;
@@ -138,7 +138,7 @@ __global__ void k_resize(const float* __restrict__ in, int ih, int iw, int c, fl
 
 // ---- a3+a4: resampler + concat on the cached 137x137x1472 map ---------------
 __global__ void k_sample_features(const float* __restrict__ f137, const float* __restrict__ xy, long long n,
-                                  float* __restrict__ out) {
+                                  float* __restrict__ out, int out_stride, int out_off) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * (FEAT_C / 4)) return;
   long long p = t / (FEAT_C / 4);
@@ -151,15 +151,16 @@ __global__ void k_sample_features(const float* __restrict__ f137, const float* _
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(o[e], __fmul_rn(c.w[q], v[e]));
   }
-  *(floatx4*)(out + (size_t)p * FEAT_C + ch) = o;
+  *(floatx4*)(out + (size_t)p * out_stride + out_off + ch) = o;
 }
 
-// ---- per-image GEMM: C[M][N] = A[M][K] . B[K][N], exact fp32 on
-// v_mfma_f32_32x32x2_f32.  128x128 tile per workgroup, 4 waves of 64x64.
+// ---- fp32 GEMM: C[M][N] = act(A[M][K] . B[K][N] + bias), exact fp32 on v_mfma_f32_32x32x2_f32.  128x128 tile
+// per workgroup, 4 waves of 64x64.  Rows of A / C are lda / ldc floats apart (N % 128 == 0, K % 16 == 0).
+// Used per image (Pmap) and by the as-written reference decoder of disn_sdf_selfcheck.
 constexpr int GT = 128, GK = 16;
-__global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, const float* __restrict__ B,
+__global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                    const float* __restrict__ bias /*[N], added to every row*/,
-                                                   float* __restrict__ C, int M, int N, int K) {
+                                                   float* __restrict__ C, int ldc, int M, int N, int K, int relu) {
   __shared__ float As[GK][GT + 4];
   __shared__ float Bs[GK][GT + 4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, c
       int idx = threadIdx.x + q * 256;       // 512 float4
       int row = idx >> 2, kq = (idx & 3) * 4;
       floatx4 v = {0, 0, 0, 0};
-      if (m0 + row < M) v = *(const floatx4*)(A + (size_t)(m0 + row) * K + k0 + kq);
+      if (m0 + row < M) v = *(const floatx4*)(A + (size_t)(m0 + row) * lda + k0 + kq);
       As[kq + 0][row] = v[0]; As[kq + 1][row] = v[1]; As[kq + 2][row] = v[2]; As[kq + 3][row] = v[3];
     }
     // B tile: 16 k x 128 cols
@@ -211,7 +212,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, c
       for (int g = 0; g < 16; ++g) {
         int row = m0 + wm + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
         int col = n0 + wn + b * 32 + r;
-        if (row < M) C[(size_t)row * N + col] = __fadd_rn(acc[a][b][g], bias[col]);
+        if (row < M) {
+          float v = __fadd_rn(acc[a][b][g], bias[col]);
+          C[(size_t)row * ldc + col] = relu ? fmaxf(v, 0.0f) : v;
+        }
       }
 }
 
@@ -223,6 +227,52 @@ __global__ void k_global_bias(const float* __restrict__ gfeat, const float* __re
   float s = 0.0f;
   for (int k = 0; k < 1024; ++k) s = fmaf(gfeat[k], Wg[(size_t)k * 512 + n], s);
   out[n] = s + b[n];
+}
+
+// ---- as-written fp32 reference decoder (disn_sdf_selfcheck) -----------------------------------------------------
+// fold1/conv1 of both streams: h1[s][n][64] = relu(p . W1 + b1), plain fp32 in k order (reference models/sdfnet.py:74,176)
+__global__ void k_ref_l1(const float* __restrict__ pts, int n, const float* __restrict__ w1g, const float* __restrict__ b1g,
+                         const float* __restrict__ w1l, const float* __restrict__ b1l, float* __restrict__ h1g,
+                         float* __restrict__ h1l) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 64) return;
+  int p = t >> 6, f = t & 63;
+  float x = pts[3 * p], y = pts[3 * p + 1], z = pts[3 * p + 2];
+  float g = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, w1g[f]), __fmul_rn(y, w1g[64 + f])), __fmul_rn(z, w1g[128 + f])), b1g[f]);
+  float l = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, w1l[f]), __fmul_rn(y, w1l[64 + f])), __fmul_rn(z, w1l[128 + f])), b1l[f]);
+  h1g[t] = fmaxf(g, 0.0f);
+  h1l[t] = fmaxf(l, 0.0f);
+}
+// the tiled global feature of models/sdfnet.py:78-82: dst[p][off + c] = g[c]
+__global__ void k_ref_tile_global(const float* __restrict__ g, int n, float* __restrict__ dst, int stride, int off) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 256) return;
+  int p = t >> 8, c = (t & 255) * 4;
+  *(floatx4*)(dst + (size_t)p * stride + off + c) = *(const floatx4*)(g + c);
+}
+// fold2/conv5 of both streams, their sum, /10 in float64 (models/sdfnet.py:88,186; model_normalization.py:204; demo.py:335)
+__global__ void k_ref_final(const float* __restrict__ h5g, const float* __restrict__ h5l, int n, const float* __restrict__ w6g,
+                            const float* __restrict__ b6g, const float* __restrict__ w6l, const float* __restrict__ b6l,
+                            float* __restrict__ out) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float g = 0.0f, l = 0.0f;
+  for (int k = 0; k < 256; ++k) {
+    g = fmaf(h5g[(size_t)p * 256 + k], w6g[k], g);
+    l = fmaf(h5l[(size_t)p * 256 + k], w6l[k], l);
+  }
+  float pred = __fadd_rn(__fadd_rn(g, b6g[0]), __fadd_rn(l, b6l[0]));
+  out[p] = (float)((double)pred / 10.0);
+}
+// res[0] = max |a - b|, res[1] = max |a| as float bits (non-negative floats order like unsigned ints); NaN counts as +inf
+__global__ void k_max_abs_diff(const float* __restrict__ a, const float* __restrict__ b, int n, unsigned* __restrict__ res) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float d = fabsf(a[p] - b[p]), m = fabsf(a[p]);
+  if (!(d == d)) d = __int_as_float(0x7f800000);
+  if (!(m == m)) m = __int_as_float(0x7f800000);
+  atomicMax(&res[0], (unsigned)__float_as_int(d));
+  atomicMax(&res[1], (unsigned)__float_as_int(m));
 }
 
 // ---- the decoder -----------------------------------------------------------
@@ -1117,6 +1167,67 @@ constexpr int MX_Q[6] = {MX_CVT_Q};
 constexpr int mx_q_start(int m) { int c = 0; for (int i = 0; i < m; ++i) c += MX_Q[i]; return c; }
 static_assert(mx_q_start(6) == 7, "7 ops per group");
 
+// The same split with the SOURCE in two other accumulator blocks (sa = features 0..31 of the group, sb = 32..63; they
+// may live in AGPRs) and the operand group x as a separate destination: used where the source blocks cannot be
+// overwritten in place (fold2/conv2 of the all-mixed decoder reads the fold2/conv1 accumulators out of the AGPR file).
+// Five stages per part -- S0 read the two elements, S1 ReLU, S2 f16 pair + fp8 of the values, S3 residuals,
+// S4 fp8 of the residuals -- and bundle t runs S4(t-4) .. S0(t); three generations of r cover the distance S0 -> S3.
+struct CvtMx5 {
+  float r[3][2];
+  float l[2];
+};
+template <int PART, int STAGE, int J, class Src>
+__device__ __forceinline__ void mx5_uop(const Src& sa, const Src& sb, XG& x, CvtMx5& st) {
+  constexpr int I = PART >> 1, blk = PART & 1, gen = PART % 3;
+  if constexpr (STAGE == 0) {
+    st.r[gen][J] = blk ? sb[J == 0 ? I : 8 + I] : sa[J == 0 ? I : 8 + I];
+    asm volatile("" : "+v"(st.r[gen][J]));   // the AGPR read happens here
+  } else if constexpr (STAGE == 1) {
+    st.r[gen][J] = relu1(st.r[gen][J]);
+  } else if constexpr (STAGE == 2) {
+    if constexpr (J == 0) {
+      const int hp = cvt_pk_f16(st.r[gen][0], st.r[gen][1]);
+      if constexpr (blk) x.b[I] = hp; else x.a[I] = hp;
+    } else {
+      if constexpr (blk) x.a[8 + I] = fp8_hi(x.a[8 + I], st.r[gen][0], st.r[gen][1]);
+      else x.a[8 + I] = fp8_lo(st.r[gen][0], st.r[gen][1]);
+    }
+  } else if constexpr (STAGE == 3) {
+    const int hp = blk ? x.b[I] : x.a[I];
+    if constexpr (J == 0) st.l[0] = res_lo(hp, st.r[gen][0]);
+    else st.l[1] = res_hi(hp, st.r[gen][1]);
+  } else {
+    if constexpr (blk) x.b[8 + I] = fp8s_hi(x.b[8 + I], st.l[0], st.l[1], XL_INV_SCALE);
+    else x.b[8 + I] = fp8s_lo(st.l[0], st.l[1], XL_INV_SCALE);
+  }
+}
+constexpr Uop mx5_uop_at(int n) {
+  int c = 0;
+  for (int t = 0; t < 16 + 4; ++t)
+    for (int stage = 4; stage >= 0; --stage) {
+      const int part = t - stage;
+      if (part < 0 || part > 15) continue;
+      for (int j = 0; j < (stage == 4 ? 1 : 2); ++j, ++c)
+        if (c == n) return Uop{part, stage, j};
+    }
+  return Uop{-1, -1, -1};
+}
+template <int N0, int CNT, class Src>
+__device__ __forceinline__ void mx5_uops(const Src& sa, const Src& sb, XG& x, CvtMx5& st) {
+  static_for<CNT>([&](auto ic) {
+    constexpr Uop u = mx5_uop_at(N0 + decltype(ic)::value);
+    static_assert(u.part >= 0, "op index out of range");
+    mx5_uop<u.part, u.stage, u.j>(sa, sb, x, st);
+  });
+}
+// ops of this split per MFMA shadow of a group_step (8 groups host one split: 18 ops per group)
+#ifndef MX5_CVT_Q
+#define MX5_CVT_Q 2, 2, 2, 2, 5, 5
+#endif
+constexpr int MX5_Q[6] = {MX5_CVT_Q};
+constexpr int mx5_q_start(int m) { int c = 0; for (int i = 0; i < m; ++i) c += MX5_Q[i]; return c; }
+static_assert(mx5_q_start(6) == 18, "18 ops per group");
+
 __device__ __forceinline__ int load_scale(const float* sp, int layer) {
   int w = ((const int*)(sp + SP_SC))[layer];
   asm volatile("" : "+v"(w));   // the MFMA takes its scales from VGPRs
@@ -1227,7 +1338,7 @@ __device__ __forceinline__ void l3_stage_mx(Pipe& pipe, Ring8& rg, intx16& acc3,
   });
 }
 
-template <bool LOCAL>
+template <bool LOCAL, bool L4MX>
 __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const float* sp,
                                                 const float* b4 /*LDS: global stream's fold2/conv1 bias*/, uint4* park,
                                                 const float* __restrict__ pmap, float px, float py, float pz, float u,
@@ -1341,7 +1452,7 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
   // chained on the same accumulator, has issued).
   XG xd;
   xd.a = as_bits(bias_init(sp + SP_B3, 64, half_of()));
-  auto chain = [&](XG& cu, XG& nx, const int m, auto with_next, auto with_pre) {
+  auto chain = [&](XG& cu, XG& nx, const int m, auto with_next, auto with_pre, auto tail) {
     constexpr bool NEXT = decltype(with_next)::value, PRE = decltype(with_pre)::value;
     if constexpr (NEXT) {
       l3_stage_mx(pipe, rg, nx.a, h2, park, sc3, [&] { nx.b = as_bits(bias_init(sp + SP_B3, 64 * m + 96, half_of())); });
@@ -1357,6 +1468,7 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
         group_step<G, true>(pipe, rg, acc4[T], cu, sc4, [&](auto mm) {
           constexpr int M = decltype(mm)::value;
           if constexpr (NEXT) mx_uops<7 * T + mx_q_start(M), MX_Q[M]>(nx, cs);
+          tail(std::integral_constant<int, T>{}, mm);
           if constexpr (PRE && T == 15 && (M == 4 || M == 5)) {
             const int h4 = 4 * half_of();
 #pragma unroll
@@ -1370,16 +1482,46 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
       });
     });
   };
+  auto no_tail = [](auto, auto) {};
 #pragma unroll 1
   for (int mm = 0; mm < 3; ++mm) {
-    chain(xc, xd, 2 * mm, std::true_type{}, std::true_type{});
-    chain(xd, xc, 2 * mm + 1, std::true_type{}, std::true_type{});
+    chain(xc, xd, 2 * mm, std::true_type{}, std::true_type{}, no_tail);
+    chain(xd, xc, 2 * mm + 1, std::true_type{}, std::true_type{}, no_tail);
   }
-  chain(xc, xd, 6, std::true_type{}, std::false_type{});
-  chain(xd, xc, 7, std::false_type{}, std::false_type{});
+  chain(xc, xd, 6, std::true_type{}, std::false_type{}, no_tail);
+  floatx16 acc5[8];
+  if constexpr (L4MX) {
+    // fold2/conv2 (512 -> 256) in the same mixed arithmetic: the fold2/conv1 accumulators are read out of the AGPR file
+    // two blocks (64 features) at a time into an operand group (ping-pong ya / yb), whose split fills the MFMA
+    // shadows of the previous group's eight group steps.  Blocks 0, 1 are final after the first stage of the last
+    // chain step and are split in the shadows of its last two stages (xc is dead there).
+    XG ya, yb;
+    CvtMx5 c5;
+    chain(xd, xc, 7, std::false_type{}, std::false_type{}, [&](auto tc, auto mc) {
+      constexpr int T = decltype(tc)::value, M = decltype(mc)::value;
+      if constexpr (T >= 8) mx5_uops<18 * (T - 8) + mx5_q_start(M), MX5_Q[M]>(acc4[0], acc4[1], ya, c5);
+    });
+    const Scales sc5 = {load_scale(sp, 3), xl_scale};
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) acc5[nb] = bias_init(sp + SP_B5, 32 * nb, half_of());
+    asm volatile("s_nop 7" ::: "memory");
+    static_for<8>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      XG& cu = (m & 1) ? yb : ya;
+      XG& nx = (m & 1) ? ya : yb;
+      static_for<8>([&](auto nc) {
+        constexpr int nb5 = decltype(nc)::value;
+        group_step<(nb5 & 3), false>(pipe, rg, acc5[nb5], cu, sc5, [&](auto mm) {
+          constexpr int M = decltype(mm)::value;
+          if constexpr (m < 7)
+            mx5_uops<18 * nb5 + mx5_q_start(M), MX5_Q[M]>(acc4[m < 7 ? 2 * m + 2 : 0], acc4[m < 7 ? 2 * m + 3 : 0], nx, c5);
+        });
+      });
+    });
+  } else {
+  chain(xd, xc, 7, std::false_type{}, std::false_type{}, no_tail);
   // fold2/conv2 (512 -> 256) on the bf16 triple, consuming the fold2/conv1 accumulators block by block (unrolled:
   // the accumulator file cannot be indexed by a loop counter)
-  floatx16 acc5[8];
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) acc5[nb] = bias_init(sp + SP_B5, 32 * nb, half_of());
   intx4 yhi[2][2], ylo[2][2];
@@ -1398,6 +1540,7 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
       });
     });
   });
+  }
   float part = 0.0f;
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) {
@@ -1417,7 +1560,7 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
 // stream and stores g + l (reference models/model_normalization.py:204), scaled if asked.  Each launch walks one
 // stream's 2.1 MiB of fragments, which stay in an XCD's 4 MiB L2; both streams in one launch (4.2 MiB, cyclic) missed
 // on every line and drew the whole stream from the Infinity Cache for each round of tiles.
-template <bool LOCAL>
+template <bool LOCAL, bool L4MX>
 __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");   // FP16_OVFL: saturating f16 / fp8 conversions
@@ -1478,7 +1621,7 @@ __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
       }
       float u, v;
       project(geom->T, x, y, z, u, v);
-      pred = stream_pass_mx<LOCAL>(pipe, rg, sp_lds + (LOCAL ? SP_MX_LDS : 0), sp_lds + 2 * SP_MX_LDS, park, a.pmap,
+      pred = stream_pass_mx<LOCAL, L4MX>(pipe, rg, sp_lds + (LOCAL ? SP_MX_LDS : 0), sp_lds + 2 * SP_MX_LDS, park, a.pmap,
                                    xr, yr, zr, u, v);
     }
     long long p = tile * 128 + pipe.wave * 32 + (pipe.lane & 31);
@@ -1503,18 +1646,22 @@ __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
 }  // namespace
 
 struct SdfState {
-  DevBuf ws, wsmx, sp, f137, pmap, wimg, wglob, b4g, b4l, tmat;
+  DevBuf ws, wsmx, wsmx4, sp, f137, pmap, wimg, wglob, b4g, b4l, tmat;
+  DevBuf wraw, gfeat, chk;   // selfcheck: the fp32 weights as given, the image's global feature, work buffers
+  size_t wraw_off[24] = {};  // float offsets of the 24 arrays (DisnDecoderWeights order) inside wraw
   int num_cu = 256;
   int decoder = DISN_DECODER_MIXED;
   bool have_weights = false, have_image = false, lds_attr_set = false, lds_attr_set_mx = false;
-  bool mixed_ok = false;      // the mixed stream could be packed (all MFMA-layer weights inside the fp16 range)
+  bool mixed_ok = false;      // the mixed streams could be packed (MFMA-layer weights of the first three layers inside the fp16 range)
+  bool mixed4_ok = false;     // ... and fold2/conv2's as well
   float mixed_bad_max = 0;    // ... else the offending max |w|
 };
 
 void disn_sdf_state_free(DisnCtx* ctx) {
   if (!ctx->sdf) return;
   SdfState* s = ctx->sdf;
-  DevBuf* all[] = {&s->ws, &s->wsmx, &s->sp, &s->f137, &s->pmap, &s->wimg, &s->wglob, &s->b4g, &s->b4l, &s->tmat};
+  DevBuf* all[] = {&s->ws, &s->wsmx, &s->wsmx4, &s->sp, &s->f137, &s->pmap, &s->wimg, &s->wglob, &s->b4g, &s->b4l, &s->tmat,
+                   &s->wraw, &s->gfeat, &s->chk};
   for (DevBuf* b : all) disn_release(*b);
   delete s;
   ctx->sdf = nullptr;
@@ -1648,7 +1795,7 @@ extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
   SdfState* s = sdf_state(ctx);
   s->have_weights = false;   // a failure below must not leave a half-packed set usable
   s->have_image = false;
-  s->mixed_ok = true;
+  s->mixed_ok = s->mixed4_ok = true;
   struct Stream { const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4, *w5, *b5, *w6, *b6; };
   const Stream st[2] = {
       {w->g_f1c1_w, w->g_f1c1_b, w->g_f1c2_w, w->g_f1c2_b, w->g_f1c3_w, w->g_f1c3_b, w->g_f2c1_w, w->g_f2c1_b,
@@ -1686,15 +1833,16 @@ extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
                             hipMemcpyHostToDevice));
     // the same layers as units of the mixed-precision kernel: fold1/conv2, fold1/conv3, fold2/conv1 (point rows) as
     // f16 + fp8 groups, fold2/conv2 as the bf16 pairs packed above
-    int sc_exp[3];
+    int sc_exp[4];
     {
-      const float* lw[3] = {q.w2, q.w3, q.w4};
-      const int lk[3] = {64, 256, 512}, ln[3] = {256, 512, 512};
-      for (int l = 0; l < 3; ++l) {
+      const float* lw[4] = {q.w2, q.w3, q.w4, q.w5};
+      const int lk[4] = {64, 256, 512, 512}, ln[4] = {256, 512, 512, 256};
+      for (int l = 0; l < 4; ++l) {
         float mx;
         layer_scale(lw[l], lk[l], ln[l], &sc_exp[l], &mx);
-        if (!(mx < 65504.0f)) {   // beyond fp16: only the bf16x3 decoder can run these weights
-          s->mixed_ok = false;
+        if (!(mx < 65504.0f)) {   // beyond fp16: the f16 product cannot hold these weights
+          s->mixed4_ok = false;
+          if (l < 3) s->mixed_ok = false;
           s->mixed_bad_max = mx;
         }
       }
@@ -1711,15 +1859,24 @@ extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
             for (int kg = 0; kg < 4; ++kg) pack_group(mxs, q.w3, 512, blk, kg, sc_exp[1]);
         for (int nb4 = 0; nb4 < 16; ++nb4) pack_group(mxs, q.w4, 512, nb4, m, sc_exp[2]);
       }
-      const size_t f2c2_pairs = 16 * 16;   // the tail of the bf16 stream: fold2/conv2
+      const size_t head = mxs.size();         // the three mixed layers; fold2/conv2 follows in either form
+      const size_t f2c2_pairs = 16 * 16;      // the tail of the bf16 stream: fold2/conv2 as bf16 pairs
       const uint8_t* tail = (const uint8_t*)frag.data() + ((size_t)PAIRS - f2c2_pairs) * 2048;
       mxs.insert(mxs.end(), tail, tail + f2c2_pairs * 2048);
       if (mxs.size() != (size_t)PAIRS * 2048) return disn_fail(ctx, DISN_E_STATE, "internal: mixed fragment stream size");
       DISN_TRY(disn_ensure(ctx, s->wsmx, (size_t)2 * PAIRS * 2048));
       DISN_HIP(ctx, hipMemcpy((char*)s->wsmx.p + (size_t)t * PAIRS * 2048, mxs.data(), mxs.size(), hipMemcpyHostToDevice));
+      if (s->mixed4_ok) {   // all-mixed decoder: fold2/conv2 as groups, k group m (64 rows) x output block nb5
+        mxs.resize(head);
+        for (int m = 0; m < 8; ++m)
+          for (int nb5 = 0; nb5 < 8; ++nb5) pack_group(mxs, q.w5, 256, nb5, m, sc_exp[3]);
+        if (mxs.size() != (size_t)PAIRS * 2048) return disn_fail(ctx, DISN_E_STATE, "internal: all-mixed fragment stream size");
+        DISN_TRY(disn_ensure(ctx, s->wsmx4, (size_t)2 * PAIRS * 2048));
+        DISN_HIP(ctx, hipMemcpy((char*)s->wsmx4.p + (size_t)t * PAIRS * 2048, mxs.data(), mxs.size(), hipMemcpyHostToDevice));
+      }
     }
     std::vector<float> sp(SP_SIZE, 0.0f);
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < 4; ++l) {
       const int e8m0 = 127 - sc_exp[l];   // the MFMA multiplies the product by 2^(byte - 127)
       memcpy(&sp[SP_SC + l], &e8m0, 4);
     }
@@ -1744,6 +1901,20 @@ extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
   DISN_TRY(upload(ctx, s->wimg, w->l_f2c1_w + (size_t)512 * 512, (size_t)FEAT_C * 512 * sizeof(float)));
   DISN_TRY(upload(ctx, s->b4g, w->g_f2c1_b, 512 * sizeof(float)));
   DISN_TRY(upload(ctx, s->b4l, w->l_f2c1_b, 512 * sizeof(float)));   // folded into Pmap by disn_sdf_set_image
+  {   // the weights as given, for the as-written fp32 reference of disn_sdf_selfcheck
+    std::vector<float> raw;
+    for (int t = 0; t < 2; ++t) {
+      const Stream& q = st[t];
+      const float* arr[12] = {q.w1, q.b1, q.w2, q.b2, q.w3, q.b3, q.w4, q.b4, q.w5, q.b5, q.w6, q.b6};
+      const size_t cnt[12] = {3 * 64, 64, 64 * 256, 256, 256 * 512, 512, (size_t)(t ? 1984 : 1536) * 512, 512, 512 * 256, 256, 256, 1};
+      for (int i = 0; i < 12; ++i) {
+        raw.resize((raw.size() + 3) & ~(size_t)3);   // 16-byte aligned arrays (float4 loads)
+        s->wraw_off[12 * t + i] = raw.size();
+        raw.insert(raw.end(), arr[i], arr[i] + cnt[i]);
+      }
+    }
+    DISN_TRY(upload(ctx, s->wraw, raw.data(), raw.size() * sizeof(float)));
+  }
   s->have_weights = true;
   s->have_image = false;
   return DISN_OK;
@@ -1751,7 +1922,7 @@ extern "C" int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w) {
 
 extern "C" int disn_sdf_set_decoder(DisnCtx* ctx, int decoder) {
   if (!ctx) return DISN_E_ARG;
-  if (decoder != DISN_DECODER_MIXED && decoder != DISN_DECODER_BF16X3)
+  if (decoder != DISN_DECODER_MIXED && decoder != DISN_DECODER_BF16X3 && decoder != DISN_DECODER_MIXED4)
     return disn_fail(ctx, DISN_E_ARG, "disn_sdf_set_decoder: unknown decoder %d", decoder);
   sdf_state(ctx)->decoder = decoder;
   return DISN_OK;
@@ -1787,10 +1958,12 @@ extern "C" int disn_sdf_set_image(DisnCtx* ctx, const float* const feat_maps[5],
                                                               (float*)s->f137.p, IMG, IMG, FEAT_C, LV_OFF[l]);
   }
   dim3 grid(512 / GT, (NPIX + GT - 1) / GT);
-  k_gemm_f32<<<grid, 256, 0, stream>>>((const float*)s->f137.p, (const float*)s->wimg.p, (const float*)s->b4l.p, (float*)s->pmap.p, NPIX, 512,
-                                       FEAT_C);
+  k_gemm_f32<<<grid, 256, 0, stream>>>((const float*)s->f137.p, FEAT_C, (const float*)s->wimg.p, (const float*)s->b4l.p,
+                                       (float*)s->pmap.p, 512, NPIX, 512, FEAT_C, 0);
   k_global_bias<<<2, 256, 0, stream>>>(global_feat, (const float*)s->wglob.p, (const float*)s->b4g.p,
                                        (float*)s->sp.p + SP_B4);
+  DISN_TRY(disn_ensure(ctx, s->gfeat, 1024 * sizeof(float)));   // kept for disn_sdf_selfcheck
+  DISN_HIP(ctx, hipMemcpyAsync(s->gfeat.p, global_feat, 1024 * sizeof(float), hipMemcpyDeviceToDevice, stream));
   DISN_HIP(ctx, hipGetLastError());
   s->have_image = true;
   return DISN_OK;
@@ -1810,18 +1983,25 @@ static int launch_decode(DisnCtx* ctx, DecodeArgs& a, const float* trans_mat, hi
   const long long tiles = a.ntiles;
   if (tiles * STAGES_PER_TILE > 0x7fffffffll) return disn_fail(ctx, DISN_E_ARG, "too many points for one launch");
   const unsigned blocks = (unsigned)(tiles < s->num_cu ? tiles : s->num_cu);
-  if (s->decoder == DISN_DECODER_MIXED) {
-    if (!s->mixed_ok)
-      return disn_fail(ctx, DISN_E_STATE, "the loaded weights reach |w| = %g, beyond the fp16 range of the mixed decoder: "
+  if (s->decoder == DISN_DECODER_MIXED || s->decoder == DISN_DECODER_MIXED4) {
+    const bool l4 = s->decoder == DISN_DECODER_MIXED4;
+    if (!(l4 ? s->mixed4_ok : s->mixed_ok))
+      return disn_fail(ctx, DISN_E_STATE, "the loaded weights reach |w| = %g, beyond the fp16 range of the mixed decoders: "
                        "select DISN_DECODER_BF16X3 (disn_sdf_set_decoder)", (double)s->mixed_bad_max);
     if (!s->lds_attr_set_mx) {
-      DISN_HIP(ctx, hipFuncSetAttribute((const void*)sdf_decode_mx<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));
-      DISN_HIP(ctx, hipFuncSetAttribute((const void*)sdf_decode_mx<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));
+      const void* fns[4] = {(const void*)sdf_decode_mx<false, false>, (const void*)sdf_decode_mx<true, false>,
+                            (const void*)sdf_decode_mx<false, true>, (const void*)sdf_decode_mx<true, true>};
+      for (const void* f : fns) DISN_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES));
       s->lds_attr_set_mx = true;
     }
-    a.ws = (const uint4*)s->wsmx.p;
-    sdf_decode_mx<false><<<blocks, 256, MX_LDS_BYTES, stream>>>(a);   // out = g
-    sdf_decode_mx<true><<<blocks, 256, MX_LDS_BYTES, stream>>>(a);    // out = g + l (scaled)
+    a.ws = (const uint4*)(l4 ? s->wsmx4.p : s->wsmx.p);
+    if (l4) {
+      sdf_decode_mx<false, true><<<blocks, 256, MX_LDS_BYTES, stream>>>(a);   // out = g
+      sdf_decode_mx<true, true><<<blocks, 256, MX_LDS_BYTES, stream>>>(a);    // out = g + l (scaled)
+    } else {
+      sdf_decode_mx<false, false><<<blocks, 256, MX_LDS_BYTES, stream>>>(a);
+      sdf_decode_mx<true, false><<<blocks, 256, MX_LDS_BYTES, stream>>>(a);
+    }
     DISN_HIP(ctx, hipGetLastError());
     return DISN_OK;
   }
@@ -1831,6 +2011,127 @@ static int launch_decode(DisnCtx* ctx, DecodeArgs& a, const float* trans_mat, hi
   }
   sdf_decode<<<blocks, 256, LDS_BYTES, stream>>>(a);
   DISN_HIP(ctx, hipGetLastError());
+  return DISN_OK;
+}
+
+
+// ---- accuracy self-check and decoder selection -------------------------------------------------------------------
+// n sample points spread over the box (additive recurrence with the generalised golden ratio of dimension 3: low
+// discrepancy, deterministic), evaluated (1) through the as-written fp32 graph -- projection, the five resized maps
+// sampled and concatenated to 1472 channels, the tiled global feature, every 1x1 convolution as an exact-fp32
+// MFMA GEMM with no algebraic shortcut (4.72 MFLOP per point) -- and (2) through the selected decoder kernel.
+static int selfcheck_run(DisnCtx* ctx, SdfState* s, const float* trans_mat, const double* sdf_params, int n,
+                         float* max_err, float* max_abs, hipStream_t stream) {
+  const size_t N = (size_t)n;
+  // work buffer layout (floats)
+  size_t off = 0;
+  auto take = [&](size_t cnt) { size_t o = off; off += (cnt + 63) & ~(size_t)63; return o; };
+  const size_t o_pts = take(N * 3), o_xy = take(N * 2), o_h1g = take(N * 64), o_h1l = take(N * 64), o_h2 = take(N * 256);
+  const size_t o_catg = take(N * 1536), o_catl = take(N * 1984), o_h4 = take(N * 512), o_h5g = take(N * 256), o_h5l = take(N * 256);
+  const size_t o_ref = take(N), o_dec = take(N), o_res = take(64), o_tm = take(64);
+  DISN_TRY(disn_ensure(ctx, s->chk, off * sizeof(float)));
+  float* B = (float*)s->chk.p;
+  std::vector<float> pts(N * 3);
+  const double g = 1.22074408460575947536;   // x^4 = x + 1
+  const double al[3] = {1.0 / g, 1.0 / (g * g), 1.0 / (g * g * g)};
+  for (size_t i = 0; i < N; ++i)
+    for (int c = 0; c < 3; ++c) {
+      double u = 0.5 + al[c] * (double)(i + 1);
+      u -= floor(u);
+      pts[3 * i + c] = (float)(sdf_params[c] + u * (sdf_params[3 + c] - sdf_params[c]));
+    }
+  DISN_HIP(ctx, hipMemcpyAsync(B + o_pts, pts.data(), N * 3 * sizeof(float), hipMemcpyHostToDevice, stream));
+  DISN_HIP(ctx, hipMemcpyAsync(B + o_tm, trans_mat, 12 * sizeof(float), hipMemcpyHostToDevice, stream));
+  DISN_HIP(ctx, hipStreamSynchronize(stream));   // pts is a local
+  const float* W = (const float*)s->wraw.p;
+  auto wp = [&](int t, int i) { return W + s->wraw_off[12 * t + i]; };   // i: w1 b1 w2 b2 w3 b3 w4 b4 w5 b5 w6 b6
+  const unsigned nb = (unsigned)((N + 255) / 256);
+  k_project<<<nb, 256, 0, stream>>>(B + o_pts, (long long)N, B + o_tm, B + o_xy);
+  const long long tq = (long long)N * (FEAT_C / 4);
+  k_sample_features<<<(unsigned)((tq + 255) / 256), 256, 0, stream>>>((const float*)s->f137.p, B + o_xy, (long long)N, B + o_catl, 1984, 512);
+  k_ref_tile_global<<<(unsigned)((N * 256 + 255) / 256), 256, 0, stream>>>((const float*)s->gfeat.p, n, B + o_catg, 1536, 512);
+  k_ref_l1<<<(unsigned)((N * 64 + 255) / 256), 256, 0, stream>>>(B + o_pts, n, wp(0, 0), wp(0, 1), wp(1, 0), wp(1, 1), B + o_h1g, B + o_h1l);
+  auto gemm = [&](const float* A, int lda, const float* Wm, const float* bias, float* C, int ldc, int Nn, int K) {
+    dim3 grid(Nn / GT, (unsigned)((N + GT - 1) / GT));
+    k_gemm_f32<<<grid, 256, 0, stream>>>(A, lda, Wm, bias, C, ldc, n, Nn, K, 1);
+  };
+  for (int t = 0; t < 2; ++t) {
+    float* cat = B + (t ? o_catl : o_catg);
+    const int ck = t ? 1984 : 1536;
+    gemm(B + (t ? o_h1l : o_h1g), 64, wp(t, 2), wp(t, 3), B + o_h2, 256, 256, 64);     // fold1/conv2
+    gemm(B + o_h2, 256, wp(t, 4), wp(t, 5), cat, ck, 512, 256);                          // fold1/conv3 -> concat[:, 0:512]
+    gemm(cat, ck, wp(t, 6), wp(t, 7), B + o_h4, 512, 512, ck);                            // fold2/conv1 on the concatenation
+    gemm(B + o_h4, 512, wp(t, 8), wp(t, 9), B + (t ? o_h5l : o_h5g), 256, 256, 512);     // fold2/conv2
+  }
+  k_ref_final<<<nb, 256, 0, stream>>>(B + o_h5g, B + o_h5l, n, wp(0, 10), wp(0, 11), wp(1, 10), wp(1, 11), B + o_ref);
+  DISN_HIP(ctx, hipGetLastError());
+  // the selected decoder on the same points (points mode, scaled like the grid)
+  DecodeArgs a{};
+  a.grid_mode = 0;
+  a.pts = B + o_pts;
+  a.pts_rot = B + o_pts;
+  a.n = n;
+  a.scale_out = 1;
+  a.out = B + o_dec;
+  DISN_TRY(launch_decode(ctx, a, trans_mat, stream));
+  DISN_HIP(ctx, hipMemsetAsync(B + o_res, 0, 2 * sizeof(unsigned), stream));
+  k_max_abs_diff<<<nb, 256, 0, stream>>>(B + o_ref, B + o_dec, n, (unsigned*)(B + o_res));
+  DISN_HIP(ctx, hipGetLastError());
+  float res[2];
+  DISN_HIP(ctx, hipMemcpyAsync(res, B + o_res, sizeof res, hipMemcpyDeviceToHost, stream));
+  DISN_HIP(ctx, hipStreamSynchronize(stream));
+  *max_err = res[0];
+  if (max_abs) *max_abs = res[1];
+  return DISN_OK;
+}
+
+static int selfcheck_args(DisnCtx* ctx, const char* who, const float* trans_mat, const double* sdf_params, int n) {
+  SdfState* s = ctx->sdf;
+  if (!s || !s->have_weights || !s->have_image)
+    return disn_fail(ctx, DISN_E_STATE, "%s needs disn_sdf_set_weights and disn_sdf_set_image first", who);
+  if (!trans_mat || !sdf_params) return disn_fail(ctx, DISN_E_ARG, "%s: null argument", who);
+  if (n < 1 || n > (1 << 16)) return disn_fail(ctx, DISN_E_ARG, "%s: n_points must be in [1, 65536]", who);
+  return DISN_OK;
+}
+
+extern "C" int disn_sdf_selfcheck(DisnCtx* ctx, const float* trans_mat, const double* sdf_params, int n_points,
+                                  float* max_abs_err, float* max_abs_sdf, void* stream) {
+  if (!ctx) return DISN_E_ARG;
+  if (!max_abs_err) return disn_fail(ctx, DISN_E_ARG, "disn_sdf_selfcheck: null output");
+  DISN_TRY(selfcheck_args(ctx, "disn_sdf_selfcheck", trans_mat, sdf_params, n_points));
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  return selfcheck_run(ctx, ctx->sdf, trans_mat, sdf_params, n_points, max_abs_err, max_abs_sdf, (hipStream_t)stream);
+}
+
+extern "C" int disn_sdf_autotune(DisnCtx* ctx, const float* trans_mat, const double* sdf_params, int n_points, float tolerance,
+                                 float margin, int* decoder_out, float errs[3], void* stream) {
+  if (!ctx) return DISN_E_ARG;
+  DISN_TRY(selfcheck_args(ctx, "disn_sdf_autotune", trans_mat, sdf_params, n_points));
+  if (!(tolerance > 0.0f) || !(margin >= 1.0f)) return disn_fail(ctx, DISN_E_ARG, "disn_sdf_autotune: tolerance must be > 0 and margin >= 1");
+  DISN_HIP(ctx, hipSetDevice(ctx->device));
+  SdfState* s = ctx->sdf;
+  const int ladder[3] = {DISN_DECODER_MIXED4, DISN_DECODER_MIXED, DISN_DECODER_BF16X3};   // cheapest first
+  const bool usable[3] = {s->mixed4_ok, s->mixed_ok, true};
+  const int before = s->decoder;
+  int chosen = -1;
+  float e[3] = {-1.0f, -1.0f, -1.0f};   // -1: not measured
+  for (int i = 0; i < 3 && chosen < 0; ++i) {
+    if (!usable[i]) continue;
+    s->decoder = ladder[i];
+    int rc = selfcheck_run(ctx, s, trans_mat, sdf_params, n_points, &e[i], nullptr, (hipStream_t)stream);
+    if (rc != DISN_OK) { s->decoder = before; return rc; }
+    if (e[i] * margin <= tolerance) chosen = ladder[i];
+  }
+  if (errs) { errs[DISN_DECODER_MIXED4] = e[0]; errs[DISN_DECODER_MIXED] = e[1]; errs[DISN_DECODER_BF16X3] = e[2]; }
+  if (chosen < 0) {
+    s->decoder = DISN_DECODER_BF16X3;
+    if (decoder_out) *decoder_out = DISN_DECODER_BF16X3;
+    return disn_fail(ctx, DISN_E_STATE, "disn_sdf_autotune: no decoder arithmetic keeps %gx margin to the %g tolerance on these "
+                     "weights and this image (measured max |error|: all-mixed %g, mixed %g, bf16x3 %g); bf16x3 stays selected",
+                     (double)margin, (double)tolerance, (double)e[0], (double)e[1], (double)e[2]);
+  }
+  s->decoder = chosen;
+  if (decoder_out) *decoder_out = chosen;
   return DISN_OK;
 }
 
@@ -1908,7 +2209,7 @@ extern "C" int disn_sample_features(DisnCtx* ctx, const float* xy, int64_t n, fl
   if (n == 0) return DISN_OK;
   DISN_HIP(ctx, hipSetDevice(ctx->device));
   long long t = (long long)n * (FEAT_C / 4);
-  k_sample_features<<<(unsigned)((t + 255) / 256), 256, 0, (hipStream_t)stream>>>((const float*)s->f137.p, xy, n, feat_out);
+  k_sample_features<<<(unsigned)((t + 255) / 256), 256, 0, (hipStream_t)stream>>>((const float*)s->f137.p, xy, n, feat_out, FEAT_C, 0);
   DISN_HIP(ctx, hipGetLastError());
   return DISN_OK;
 }

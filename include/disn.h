@@ -79,7 +79,24 @@ int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w);
  * Takes effect at the next disn_sdf_grid / disn_sdf_points. */
 #define DISN_DECODER_MIXED 0
 #define DISN_DECODER_BF16X3 1
+#define DISN_DECODER_MIXED4 2 /* the fp16 + 2 x fp8 scheme on fold2/conv2 as well: 0.89x the matrix time of MIXED, the
+                                 smallest accuracy margin of the three -- meant to be chosen by disn_sdf_autotune */
 int disn_sdf_set_decoder(DisnCtx* ctx, int decoder);
+
+/* Accuracy self-check (no counterpart in the reference, whose graph is plain fp32 and needs none): n_points
+ * sample points spread over the sdf_params box are evaluated through the AS-WRITTEN fp32 graph on the device
+ * (reference models/model_normalization.py:169-206,241-251, models/sdfnet.py:69-92,171-190: projection, five
+ * resized maps sampled and concatenated, tiled global feature, every 1x1 convolution as an exact fp32 GEMM, no
+ * algebraic shortcut) and through the selected decoder; *max_abs_err = max |difference| of the two SDFs (after
+ * the /10, i.e. in the units of the 1e-4 tolerance), *max_abs_sdf (may be NULL) = max |SDF|.  NaN/inf read as
+ * +inf.  Needs disn_sdf_set_weights + disn_sdf_set_image.  SYNCHRONOUS; about 1 ms for 4096 points. */
+int disn_sdf_selfcheck(DisnCtx* ctx, const float* trans_mat, const double* sdf_params, int n_points,
+                       float* max_abs_err, float* max_abs_sdf, void* stream);
+/* Decoder selection by measurement: runs the self-check for DISN_DECODER_MIXED4, _MIXED, _BF16X3 in this order
+ * (cheapest first) and selects the first whose error x margin stays within `tolerance`; errs (may be NULL) is
+ * indexed by decoder id, -1 = not measured.  If none qualifies, bf16x3 is selected and DISN_E_STATE returned. */
+int disn_sdf_autotune(DisnCtx* ctx, const float* trans_mat, const double* sdf_params, int n_points,
+                      float tolerance, float margin, int* decoder_out, float errs[3], void* stream);
 
 /* Per-image constants.  feat_maps = the five VGG end points conv1_2, conv2_2,
  * conv3_3, conv4_3, conv5_3 as DEVICE fp32 NHWC at native resolution

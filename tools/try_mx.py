@@ -20,21 +20,22 @@ for name, w in (("xavier0", synth.decoder_weights(seed=0)), ("xavier0_f16w", w16
     rng = np.random.default_rng(1)
     pts = rng.uniform(-1, 1, size=(4096 + 77, 3)).astype(np.float32)
     ref = net.sdf_points(pts, pts, synth.GT_TRANS_MAT, maps, gf, w, dtype=torch.float64)
-    for dec in ("bf16x3", "mixed"):
+    for dec in ("bf16x3", "mixed", "mixed4"):
         ctx.set_decoder(dec)
         got = ctx.sdf_points(synth.GT_TRANS_MAT, pts).cpu().numpy()
         torch.cuda.synchronize()
         err = np.abs(got - ref)
-        print("%-14s %-7s max |err| raw %.3e (after /10: %.3e), nan %d, max |ref| %.3f" %
-              (name, dec, err.max(), err.max() / 10, int(np.isnan(got).sum()), np.abs(ref).max()), flush=True)
-        if dec == "mixed" and err.max() > 1e-3:
-            bad = np.argsort(-err)[:8]
-            print("   worst idx", bad, "got", got[bad], "ref", ref[bad])
+        sc = ctx.selfcheck(synth.GT_TRANS_MAT)
+        print("%-14s %-7s max |err| raw %.3e (after /10: %.3e), nan %d, max |ref| %.3f; device selfcheck err %.3e max|sdf| %.3f" %
+              (name, dec, err.max(), err.max() / 10, int(np.isnan(got).sum()), np.abs(ref).max(), sc[0], sc[1]), flush=True)
+    ctx.set_decoder("auto")
+    ctx.sdf_points(synth.GT_TRANS_MAT, pts)
+    print("   autotune:", ctx.decoder_report, flush=True)
 if len(sys.argv) > 1:
     res = int(sys.argv[1])
     out = torch.empty((res + 1, res + 1, res + 1), dtype=torch.float32, device=ctx.device)
     for rnd in range(3):
-        for dec in ("bf16x3", "mixed"):
+        for dec in ("bf16x3", "mixed", "mixed4"):
             ctx.set_decoder(dec)
             ctx.sdf_grid(synth.GT_TRANS_MAT, res, out=out)
             torch.cuda.synchronize()
