@@ -108,6 +108,16 @@ class MeshPipeline:
         ev = (lambda: self._mark()) if self.time_decode else (lambda: None)
         i0 = ev()
         ctx.set_image(feats, gfeat)
+        if self.world > 1 and ctx.auto_decoder and not ctx._tuned:
+            # every rank measures the same features with the same kernels; rank 0's choice is taken anyway, so that
+            # slab seams can never meet two arithmetics
+            ctx.autotune(trans_mat, sdf_params)
+            pick = torch.tensor([ctx.DECODERS[ctx.decoder]], dtype=torch.int32, device=ctx.device)
+            self.dist.broadcast(pick, src=0)
+            name = ctx.DECODER_NAMES[int(pick.item())]
+            if name != ctx.decoder:
+                ctx.set_decoder(name)
+                ctx.auto_decoder, ctx._tuned = True, True
         i1 = ev()
         if i0 is not None:
             self.image_events.append((i0, i1))

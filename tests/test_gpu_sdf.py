@@ -129,7 +129,7 @@ def test_state_errors(ctx):
     c.close()
 
 
-@pytest.mark.parametrize("decoder", ["mixed", "bf16x3"])
+@pytest.mark.parametrize("decoder", ["mixed4", "mixed", "bf16x3"])
 @pytest.mark.parametrize("res,z0,z1", [(1, 0, 1), (2, 1, 2), (3, 0, 3), (7, 0, 7), (8, 0, 8), (12, 1, 11), (20, 0, 3), (33, 5, 5),
                                         (40, 0, 40), (64, 0, 64), (64, 7, 38)])
 def test_grid_tiling_matches_points_mode(ctx, model, decoder, res, z0, z1):
@@ -149,28 +149,31 @@ def test_grid_tiling_matches_points_mode(ctx, model, decoder, res, z0, z1):
         want = (raw.double() / 10.0).float().reshape(z1 - z0 + 1, res + 1, res + 1)
         assert torch.equal(got, want)
     finally:
-        ctx.set_decoder("mixed")
+        ctx.set_decoder("auto")
 
 
 def test_decoders_agree_and_meet_tolerance(ctx, model):
-    """Both decoder arithmetics (disn_sdf_set_decoder) against the float64 oracle on the same points."""
+    """All three decoder arithmetics (disn_sdf_set_decoder) against the float64 oracle on the same points."""
     maps, gf, w = model
     rng = np.random.default_rng(21)
     pts = rng.uniform(-1, 1, (4096, 3)).astype(np.float32)
     want64 = net.sdf_points(pts, pts, net.GT_TRANS_MAT, maps, gf, w, dtype=torch.float64)
     try:
-        for name in ("mixed", "bf16x3"):
+        for name in ("mixed4", "mixed", "bf16x3"):
             ctx.set_decoder(name)
             ctx.set_weights(w)
             ctx.set_image(maps, gf)
             got = ctx.sdf_points(net.GT_TRANS_MAT, pts).cpu().numpy()
             err = np.abs(got - want64).max() / 10.0
-            print("%s: max err after /10 %.2e" % (name, err))
+            chk, mx = ctx.selfcheck(net.GT_TRANS_MAT)
+            print("%s: max err after /10 %.2e; device self-check %.2e (max |sdf| %.3f)" % (name, err, chk, mx))
             assert err <= TOL_SDF
+            # the device's own measurement (as-written fp32 graph, other sample points) tells the same story
+            assert 0.1 * err <= chk <= 10 * err + 5e-7
         with pytest.raises(Exception):
             ctx.set_decoder("fp4")
     finally:
-        ctx.set_decoder("mixed")
+        ctx.set_decoder("auto")
 
 
 def test_mixed_decoder_adversarial_weight_scales(ctx):
@@ -206,3 +209,94 @@ def test_mixed_decoder_adversarial_weight_scales(ctx):
     ctx.set_weights(w2)
     ctx.set_image(maps, gf)
     assert np.isfinite(ctx.sdf_points(net.GT_TRANS_MAT, pts).cpu().numpy()).all()
+    ctx.set_decoder("auto")
+
+
+def _measured(ctx):
+    out = {}
+    for name in ("mixed4", "mixed", "bf16x3"):
+        ctx.set_decoder(name)
+        out[name] = ctx.selfcheck(net.GT_TRANS_MAT)[0]
+    ctx.set_decoder("auto")
+    return out
+
+
+def test_autotune_takes_the_cheapest_arithmetic_that_keeps_the_margin(ctx):
+    """disn_sdf_autotune on the adversarial weight set: the ladder all-mixed -> mixed -> bf16x3 is walked by MEASURED
+    error against the as-written fp32 graph; margins placed between the measured errors must move the choice, a
+    margin nobody meets is an error (bf16x3 stays selected), and the chosen arithmetic meets the tolerance against
+    the float64 oracle on other points."""
+    from disn_amd.api import DisnError
+    maps, gf = net.synthetic_features(seed=6)
+    w = net.xavier_decoder_weights(seed=6, bias_scale=0.3)
+    rng = np.random.default_rng(6)
+    for k in list(w):
+        if k.endswith(("f1c3_w", "f2c1_w", "f2c2_w")):
+            w[k] = (w[k] * np.exp(rng.normal(0, 0.7, (1, w[k].shape[1]))).astype(np.float32)).astype(np.float32)
+    pts = rng.uniform(-1, 1, (2048, 3)).astype(np.float32)
+    raw64 = net.sdf_points(pts, pts, net.GT_TRANS_MAT, maps, gf, w, dtype=torch.float64)
+    for k in list(w):
+        if k.endswith("f2c5_w"):
+            w[k] = w[k] * np.float32(10.0 / np.abs(raw64).max())
+    want64 = net.sdf_points(pts, pts, net.GT_TRANS_MAT, maps, gf, w, dtype=torch.float64)
+    ctx.set_weights(w)
+    ctx.set_image(maps, gf)
+    e = _measured(ctx)
+    print("measured:", e)
+    assert e["bf16x3"] < e["mixed4"] and e["mixed"] < e["mixed4"]
+    tol = 1e-4
+    rep = ctx.autotune(net.GT_TRANS_MAT, margin=0.9 * tol / e["mixed4"])     # all-mixed just qualifies
+    assert rep["chosen"] == ctx.decoder == "mixed4" and rep["errors"]["mixed"] is None
+    rep = ctx.autotune(net.GT_TRANS_MAT, margin=1.1 * tol / e["mixed4"])     # all-mixed just fails: next rung
+    assert rep["chosen"] in ("mixed", "bf16x3") and rep["errors"]["mixed4"] == pytest.approx(e["mixed4"], rel=1e-6)
+    with pytest.raises(DisnError, match="no decoder arithmetic"):
+        ctx.autotune(net.GT_TRANS_MAT, margin=1.1 * tol / min(e.values()))
+    assert ctx.decoder == "bf16x3"
+    # default policy (5x): whatever it picks keeps the tolerance against the float64 oracle
+    ctx.set_decoder("auto")
+    got = ctx.sdf_points(net.GT_TRANS_MAT, pts).cpu().numpy()
+    rep = ctx.decoder_report
+    err = np.abs(got - want64).max() / 10.0
+    print("default policy chose %s (measured %s); max err vs float64 oracle %.2e" % (rep["chosen"], rep["errors"], err))
+    assert rep["errors"][rep["chosen"]] * 5.0 <= tol and err <= TOL_SDF
+
+
+def test_autotune_catches_activations_beyond_fp8_range(ctx):
+    """Activations of several thousand: fp8(x) saturates at 448 and the mixed decoders silently lose their correction
+    terms (about fp16-product accuracy).  The self-check must see that (its figure agrees with the float64 oracle's)
+    and the automatic choice must either stay inside the tolerance or refuse -- never degrade silently."""
+    from disn_amd.api import DisnError
+    maps, gf = net.synthetic_features(seed=8)
+    w = net.xavier_decoder_weights(seed=8, bias_scale=0.1)
+    for k in list(w):
+        if k.endswith("f1c1_w"):
+            w[k] = w[k] * np.float32(2500.0)          # h1 up to ~2000, h2 / h3 of the same order
+    rng = np.random.default_rng(8)
+    pts = rng.uniform(-1, 1, (4096, 3)).astype(np.float32)
+    raw64 = net.sdf_points(pts, pts, net.GT_TRANS_MAT, maps, gf, w, dtype=torch.float64)
+    for k in list(w):
+        if k.endswith("f2c5_w"):
+            w[k] = w[k] * np.float32(5.0 / np.abs(raw64).max())      # |SDF| up to 0.5 like a trained network
+    want64 = net.sdf_points(pts, pts, net.GT_TRANS_MAT, maps, gf, w, dtype=torch.float64) / 10.0
+    ctx.set_weights(w)
+    ctx.set_image(maps, gf)
+    true_err = {}
+    for name in ("mixed4", "mixed", "bf16x3"):
+        ctx.set_decoder(name)
+        got = ctx.sdf_points(net.GT_TRANS_MAT, pts).cpu().numpy() / 10.0
+        true_err[name] = float(np.abs(got - want64).max())
+    e = _measured(ctx)
+    print("vs float64 oracle:", true_err, " device self-check:", e)
+    assert true_err["mixed"] > 5 * true_err["bf16x3"]                  # the regime the advisor described
+    for name in e:
+        assert 0.25 * true_err[name] <= e[name] <= 4 * true_err[name]
+    ctx.set_decoder("auto")
+    try:
+        got = ctx.sdf_points(net.GT_TRANS_MAT, pts).cpu().numpy() / 10.0
+    except DisnError as ex:
+        print("refused:", ex)
+        assert "no decoder arithmetic" in str(ex) and min(e.values()) * 5.0 > 1e-4
+    else:
+        print("chose", ctx.decoder)
+        assert float(np.abs(got - want64).max()) <= TOL_SDF and e[ctx.decoder] * 5.0 <= 1e-4
+    ctx.set_decoder("auto")
