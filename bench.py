@@ -215,7 +215,8 @@ def main():
                                    "OBJ text excluded (other_kernels.mesh_output)" % (res, world),
                        "sdf_res": res, "decoder": decoder, "decoder_selection": args.decoder, "points": points, "mesh_vertices": int(verts.shape[0]),
                        "mesh_triangles": int(tris.shape[0]), "iso": iso,
-                       "per_gpu_points_evaluated": local_pts, "halo": pipe.halo if world > 1 else None},
+                       "per_gpu_points_evaluated": local_pts, "halo": pipe.halo if world > 1 else None,
+                       "stitch": pipe.last_stitch},
             "roofline": {"bound": "mfma", "kernel": "sdf_decode" if decoder == "bf16x3" else "sdf_decode_mx", "achieved": alg_tflops, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": alg_tflops / PEAK_BF16_TFLOPS, "traffic": None,
                          "kernel_ms": dec_ms, "launches_per_pass": 1 if decoder == "bf16x3" else 2,

@@ -53,6 +53,7 @@ class Context:
         self._tuned = False
         self.decoder = "mixed"         # what the library runs right now (its own default until tuned / set)
         self.decoder_report = None     # last autotune: {"chosen", "errors", "tolerance", "margin"}
+        self.weights_version = 0       # bumped by set_weights (MeshPipeline re-agrees on the decoder across ranks)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -84,6 +85,7 @@ class Context:
                     setattr(st, name, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
         self._check(self.lib.disn_sdf_set_weights(self._h, ctypes.byref(st)), "disn_sdf_set_weights")
         self._tuned = False            # new weights: the arithmetic is measured again
+        self.weights_version += 1
 
     DECODERS = {"mixed": 0, "bf16x3": 1, "mixed4": 2}
     DECODER_NAMES = {v: k for k, v in DECODERS.items()}

@@ -4,14 +4,18 @@ ranks of a torch.distributed group (one process per GPU; backend "nccl" is RCCL)
 Replaces the body of the reference's test_one_epoch + create_obj
 (reference: demo/demo.py:281-369) without the host round trips, the .dist file
 hop and the subprocess.  Multi-GPU exchange: one broadcast of
-the image features, one all-gather of three counts per rank, then each rank
-sends its slab mesh (already carrying global vertex indices) to rank 0, which
-orders the triangles with one device sort.  There is no all-reduce anywhere.
+the image features, one all-gather of three counts per rank; then every rank
+emits its slab with final global vertex indices, ORDERS ITS OWN TRIANGLES on its
+own GPU, and sends the sorted pieces to rank 0, which only places them: the
+global lexicographic order is the centre-vertex-first runs of the slabs in
+reverse slab order followed by the edge-vertex-first runs in slab order
+(triangle_segments).  Rank 0 checks the seams between the pieces and re-sorts
+only if one is out of order.  There is no all-reduce anywhere.
 """
 import numpy as np
 import torch
 
-from .slabs import slab_bases, slab_ranges, split_layers
+from .slabs import slab_bases, slab_plan, slab_ranges
 
 
 class _Comm:
@@ -66,6 +70,37 @@ class _Comm:
                 req.wait()
 
 
+def triangle_segments(counts, n_centre_first):
+    """Where the sorted triangle lists of the slabs go in the global list.  counts[g] = (n_centre, n_edge, n_tri),
+    n_centre_first[g] = how many of slab g's triangles start with a centre vertex (they lead its sorted list,
+    centre indices being smaller than every edge index).  Global order (App. B.6 with the index bases of
+    slab_bases): centre vertices are numbered slab G-1 first, so the centre-first runs come in REVERSE slab order,
+    then the edge-first runs in slab order.  Returns [(centre_first_offset, edge_first_offset)] per slab."""
+    world = len(counts)
+    off, cf_off = 0, [0] * world
+    for g in reversed(range(world)):
+        cf_off[g] = off
+        off += n_centre_first[g]
+    ef_off = [0] * world
+    for g in range(world):
+        ef_off[g] = off
+        off += counts[g][2] - n_centre_first[g]
+    return list(zip(cf_off, ef_off))
+
+
+def seams_in_order(gt, pieces):
+    """pieces = [(offset, length)] of sorted runs laid out in gt (device [T,3] int32), in global order: True iff the
+    last triangle of every non-empty piece is lexicographically below the first triangle of the next one."""
+    runs = sorted((o, n) for o, n in pieces if n > 0)
+    if len(runs) < 2:
+        return True
+    idx = []
+    for (o, n), (o2, _) in zip(runs, runs[1:]):
+        idx += [o + n - 1, o2]
+    rows = gt[torch.tensor(idx, device=gt.device)].cpu().tolist()
+    return all(tuple(a) < tuple(b) for a, b in zip(rows[0::2], rows[1::2]))
+
+
 class MeshPipeline:
     def __init__(self, ctx, rank=0, world=1, dist=None, halo="exchange"):
         """halo: how a slab gets its one halo plane below and two above --
@@ -82,6 +117,8 @@ class MeshPipeline:
         self.mc_events = []         # ... around marching cubes (count + emit + sort), single GPU
         self.time_decode = False
         self.last_sdf = None
+        self.last_stitch = None     # multi-GPU, rank 0: "placed" (sorted pieces only placed) or "resorted" (a seam was out of order)
+        self._agreed_weights = None
 
     @staticmethod
     def _mark():
@@ -108,25 +145,24 @@ class MeshPipeline:
         ev = (lambda: self._mark()) if self.time_decode else (lambda: None)
         i0 = ev()
         ctx.set_image(feats, gfeat)
-        if self.world > 1 and ctx.auto_decoder and not ctx._tuned:
-            # every rank measures the same features with the same kernels; rank 0's choice is taken anyway, so that
-            # slab seams can never meet two arithmetics
-            ctx.autotune(trans_mat, sdf_params)
+        if self.world > 1 and self._agreed_weights != ctx.weights_version:
+            # once per weight set (set_weights is called by every rank alike, so every rank gets here together):
+            # each rank measures the same broadcast features with the same kernels, and rank 0's choice of decoder
+            # arithmetic is taken by all, so that slab seams can never meet two arithmetics
+            if ctx.auto_decoder and not ctx._tuned:
+                ctx.autotune(trans_mat, sdf_params)
             pick = torch.tensor([ctx.DECODERS[ctx.decoder]], dtype=torch.int32, device=ctx.device)
             self.dist.broadcast(pick, src=0)
             name = ctx.DECODER_NAMES[int(pick.item())]
             if name != ctx.decoder:
+                auto = ctx.auto_decoder
                 ctx.set_decoder(name)
-                ctx.auto_decoder, ctx._tuned = True, True
+                ctx.auto_decoder, ctx._tuned = auto, True
+            self._agreed_weights = ctx.weights_version
         i1 = ev()
         if i0 is not None:
             self.image_events.append((i0, i1))
-        lo, hi, own0, own1 = slab_ranges(nz, self.world)[self.rank] if self.world > 1 else (0, nz, 0, nz)
-        core0, core1 = lo, hi            # planes this rank evaluates itself
-        if self.world > 1 and self.halo == "exchange":
-            b = split_layers(nz, self.world)
-            if len(b) - 1 == self.world and min(b[g + 1] - b[g] for g in range(self.world)) >= 2:
-                core0, core1 = b[self.rank], (nz if self.rank == self.world - 1 else b[self.rank + 1])
+        lo, hi, own0, own1, core0, core1 = slab_plan(nz, self.world, self.rank, self.halo)   # core: planes evaluated here
         if self.time_decode:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -167,31 +203,46 @@ class MeshPipeline:
         allc = [tuple(int(v) for v in c.tolist()) for c in allc]
         bases = slab_bases(allc)
         cb, eb = bases[self.rank]
-        verts, tris = ctx.mc_emit(sdf_params, centre_base=cb, edge_base=eb, sort=False)
         c_total = sum(c[0] for c in allc)
         v_total = c_total + sum(c[1] for c in allc)
         t_total = sum(c[2] for c in allc)
         nc0, ne0, nt0 = allc[self.rank]
+        # every rank orders its own triangles (global indices) on its own GPU ...
+        verts, tris = ctx.mc_emit(sdf_params, centre_base=cb, edge_base=eb, sort=True)
+        ncf = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+        if nt0:
+            ncf[0] = (tris[:, 0] < c_total).sum()
+        allf = [torch.empty_like(ncf) for _ in range(self.world)]
+        self.dist.all_gather(allf, ncf)
+        allf = [int(f.item()) for f in allf]
+        seg = triangle_segments(allc, allf)
+        f0 = allf[self.rank]
         if self.rank != 0:
-            # three pieces, each contiguous at the receiver: centre vertices, edge vertices, triangles
-            self.dist.exchange([(verts[:nc0], 0), (verts[nc0:], 0), (tris, 0)], [])
+            # ... and ships four pieces, each contiguous at the receiver: centre vertices, edge vertices,
+            # centre-first triangles, edge-first triangles
+            self.dist.exchange([(verts[:nc0], 0), (verts[nc0:], 0), (tris[:f0], 0), (tris[f0:], 0)], [])
             return None, None
         gv = torch.empty((v_total, 3), dtype=torch.float64, device=ctx.device)
         gt = torch.empty((t_total, 3), dtype=torch.int32, device=ctx.device)
-        recvs, t_off = [], 0
+        recvs, pieces = [], []
         for r in range(self.world):
             nc, ne, nt = allc[r]
             cbr, ebr = bases[r]
+            cfo, efo = seg[r]
+            pieces += [(cfo, allf[r]), (efo, nt - allf[r])]
             if r == 0:
                 gv[cbr:cbr + nc] = verts[:nc]          # centre vertices: slabs in reverse order
                 gv[ebr:ebr + ne] = verts[nc:]          # edge vertices: slab order
-                gt[t_off:t_off + nt] = tris
+                gt[cfo:cfo + f0] = tris[:f0]
+                gt[efo:efo + nt - f0] = tris[f0:]
             else:
-                recvs += [(gv[cbr:cbr + nc], r), (gv[ebr:ebr + ne], r), (gt[t_off:t_off + nt], r)]
-            t_off += nt
+                recvs += [(gv[cbr:cbr + nc], r), (gv[ebr:ebr + ne], r), (gt[cfo:cfo + allf[r]], r),
+                          (gt[efo:efo + nt - allf[r]], r)]
         self.dist.exchange([], recvs)
-        if t_total:
+        self.last_stitch = "placed"
+        if not seams_in_order(gt, pieces):             # not expected (see triangle_segments); one global sort repairs it
             ctx.sort_triangles(gt, max(v_total, 1))
+            self.last_stitch = "resorted"
         return gv, gt
 
 
@@ -225,15 +276,24 @@ def mesh_by_slabs(ctx, trans_mat, res, iso, nslabs, sdf_params=(-1, -1, -1, 1, 1
     v_total = c_total + sum(c[1] for c in counts)
     t_total = sum(c[2] for c in counts)
     gv = torch.empty((v_total, 3), dtype=torch.float64, device=ctx.device)
-    gt = torch.empty((t_total, 3), dtype=torch.int32, device=ctx.device)
-    t_off = 0
+    parts = []
     for (lo, hi, own0, own1), sdf, (nc, ne, nt), (cb, eb) in zip(ranges, grids, counts, bases):
         ctx.mc_count(sdf, iso, z_offset=lo, nz_global=nz, own=(own0, own1))
-        pv, pt = ctx.mc_emit(sdf_params, centre_base=cb, edge_base=eb, sort=False)
+        pv, pt = ctx.mc_emit(sdf_params, centre_base=cb, edge_base=eb, sort=True)   # each slab sorts its own list
         gv[cb:cb + nc] = pv[:nc]
         gv[eb:eb + ne] = pv[nc:]
-        gt[t_off:t_off + nt] = pt
-        t_off += nt
-    if t_total:
+        parts.append((pt, int((pt[:, 0] < c_total).sum().item()) if nt else 0))
+    seg = triangle_segments(counts, [f for _, f in parts])
+    gt = torch.empty((t_total, 3), dtype=torch.int32, device=ctx.device)
+    pieces = []
+    for (pt, f), (cfo, efo) in zip(parts, seg):
+        gt[cfo:cfo + f] = pt[:f]
+        gt[efo:efo + len(pt) - f] = pt[f:]
+        pieces += [(cfo, f), (efo, len(pt) - f)]
+    del parts
+    info = {"stitch": "placed"}
+    if not seams_in_order(gt, pieces):
         ctx.sort_triangles(gt, max(v_total, 1))
+        info["stitch"] = "resorted"
+    mesh_by_slabs.last_info = info
     return gv, gt

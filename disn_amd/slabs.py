@@ -34,6 +34,23 @@ def slab_ranges(nz, nslab):
     return out
 
 
+def slab_plan(nz, world, rank, halo="exchange"):
+    """What rank `rank` of `world` does for an nz-plane grid: (lo, hi, own0, own1, core0, core1).
+    [lo, hi) = global planes its marching cubes needs (slab_ranges), [core0, core1) = the planes it evaluates
+    itself.  halo="exchange": only its own planes (the halo planes come from the neighbours' all-gather), which
+    needs every rank to hold at least two planes of its own -- otherwise, and with halo="recompute", every rank
+    evaluates its whole [lo, hi) range and no halo collective runs (the decision is the same on every rank)."""
+    if world <= 1:
+        return 0, nz, 0, nz, 0, nz
+    lo, hi, own0, own1 = slab_ranges(nz, world)[rank]
+    core0, core1 = lo, hi
+    if halo == "exchange":
+        b = split_layers(nz, world)
+        if len(b) - 1 == world and min(b[g + 1] - b[g] for g in range(world)) >= 2:
+            core0, core1 = b[rank], (nz if rank == world - 1 else b[rank + 1])
+    return lo, hi, own0, own1, core0, core1
+
+
 def slab_bases(counts):
     """counts[g] = (n_centre, n_edge, n_tri) per slab (in slab order).  Returns
     [(centre_base, edge_base)]: centre vertices come first globally in

@@ -41,7 +41,7 @@ v, t = pipe.run(feats, gfeat, synth.GT_TRANS_MAT, res, iso, bbox)
 torch.cuda.synchronize()
 if rank == 0:
     np.savez(sys.argv[1], tris_equal=torch.equal(t, t1), verts_equal=torch.equal(v, v1), n_tris=t.shape[0],
-             points=pipe.last_points, planes=pipe.last_sdf.shape[0])
+             points=pipe.last_points, planes=pipe.last_sdf.shape[0], stitch=pipe.last_stitch, decoder=ctx.decoder)
 dist.barrier()
 dist.destroy_process_group()
 ctx.close()

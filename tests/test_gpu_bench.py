@@ -41,3 +41,22 @@ def test_bench_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["sdf_res"] == 40 and d["config"]["points"] == 41 ** 3
     assert d["config"]["mesh_triangles"] > 0 and d["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("res", [40, 12])
+def test_bench_eight_ranks(res):
+    """The driver's scaling run: `bench.py --gpus 8` (eight z-slabs, here rehearsed over gloo on the one GPU of the test
+    box with a small --res).  sdf_res 40: five voxel layers per rank, halo planes exchanged; sdf_res 12: some ranks own
+    a single plane, so every rank recomputes its halo instead."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["DISN_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--res", str(res), "--steps", "1",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["sdf_res"] == res and d["config"]["points"] == (res + 1) ** 3
+    assert d["config"]["mesh_triangles"] > 0 and d["scaling"] == "weak" and d["config"]["stitch"] == "placed"
+    if res == 40:
+        assert d["config"]["per_gpu_points_evaluated"] == 5 * 41 * 41          # rank 0: exactly its own five planes

@@ -106,6 +106,7 @@ def _slabs_equal_single_pass(ctx, res, nslabs, seed):
     del sdf
     v8, t8 = mesh_by_slabs(ctx, synth.GT_TRANS_MAT, res, iso, nslabs)
     torch.cuda.synchronize()
+    assert mesh_by_slabs.last_info["stitch"] == "placed"      # slab-sorted pieces in place, no global sort
     assert len(t1) > 100000 * (res // 256) ** 2
     assert torch.equal(t1, t8)
     assert torch.equal(v1, v8)

@@ -46,6 +46,7 @@ def test_slab_sharded_pipeline_equals_single_rank(world, halo, tmp_path):
     subprocess.run(cmd, check=True, env=env, timeout=300, cwd=ROOT)
     z = np.load(out + ".npz")
     assert bool(z["tris_equal"]) and bool(z["verts_equal"]) and int(z["n_tris"]) > 100
+    assert str(z["stitch"]) == "placed"      # every rank sorted its own triangles; rank 0 only placed the pieces
     # rank 0 of a 31-plane grid: with the exchange it evaluates only its own planes, the halo comes from rank 1
     own = (30 * 1) // world
     assert int(z["planes"]) == own + 2

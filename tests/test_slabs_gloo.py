@@ -119,3 +119,109 @@ def test_batched_mesh_gather_lands_in_place(world, tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_exchange_worker, args=(world, port, out), nprocs=world, join=True)
     assert open(out).read() == "ok"
+
+
+@pytest.mark.parametrize("nslab", [2, 3, 8])
+def test_sorted_slab_lists_only_need_placing(nslab):
+    """The multi-GPU stitch without the rank-0 sort (pipeline.triangle_segments): every slab sorts its own triangles
+    (global indices); the centre-first runs in reverse slab order followed by the edge-first runs in slab order ARE
+    the single-pass list.  CPU restatement on a noise field full of centre vertices."""
+    from disn_amd.pipeline import triangle_segments
+    from disn_amd.slabs import slab_bases, slab_ranges
+    from oracle import mc
+    g = fields.noise_field((26, 9, 10), seed=5)
+    ref = mc.marching_cubes(g, iso=0.02)
+    assert ref["n_centre"] > 10
+    slabs = [mc.marching_cubes_slab(g, lo, hi, o0, o1, iso=0.02) for lo, hi, o0, o1 in slab_ranges(g.shape[0], nslab)]
+    counts = [tuple(int(c) for c in s.counts) for s in slabs]
+    c_total = sum(c[0] for c in counts)
+    lists, ncf = [], []
+    for s, (cb, eb) in zip(slabs, slab_bases(counts)):
+        _, t, _ = s.emit(cb, eb)
+        t = t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))] if len(t) else t
+        lists.append(t)
+        ncf.append(int((t[:, 0] < c_total).sum()) if len(t) else 0)
+    out = np.full((sum(c[2] for c in counts), 3), -1, np.int32)
+    for t, f, (cfo, efo) in zip(lists, ncf, triangle_segments(counts, ncf)):
+        out[cfo:cfo + f] = t[:f]
+        out[efo:efo + len(t) - f] = t[f:]
+    assert np.array_equal(out, ref["tris"])
+    assert sum(ncf) > 10
+
+
+def test_slab_plan_world_8_and_thin_slabs():
+    """Rehearsal of the 8-rank configurations the driver launches (bench.py --gpus 8: sdf_res 512; demo at 1024) and of
+    grids too small for them: with halo exchange every rank evaluates exactly its own planes and together they cover
+    the grid once; when a rank would own fewer than two planes ALL ranks fall back to evaluating their halo too."""
+    from disn_amd.slabs import slab_plan
+    for res in (512, 1024, 64, 16):
+        nz = res + 1
+        plans = [slab_plan(nz, 8, r) for r in range(8)]
+        cores = [(p[4], p[5]) for p in plans]
+        assert cores[0][0] == 0 and cores[-1][1] == nz
+        assert all(a[1] == b[0] for a, b in zip(cores, cores[1:]))            # evaluated exactly once
+        for lo, hi, o0, o1, c0, c1 in plans:
+            assert lo <= c0 < c1 <= hi and 0 <= o0 < o1 <= hi - lo
+            assert hi - c1 <= 2 and c0 - lo <= 1                              # halo: one plane below, two above
+    for res in (8, 12, 15):                                                   # some rank owns a single plane
+        plans = [slab_plan(res + 1, 8, r) for r in range(8)]
+        assert all((p[4], p[5]) == (p[0], p[1]) for p in plans)               # everyone recomputes its halo
+    assert all(slab_plan(41, 8, r, halo="recompute")[4:] == slab_plan(41, 8, r, halo="recompute")[:2] for r in range(8))
+    assert slab_plan(33, 1, 0) == (0, 33, 0, 33, 0, 33)
+
+
+def _empty_exchange_worker(rank, world, port, tmp):
+    """A slab whose mesh is empty (no surface in its planes) sends nothing; the others' pieces still land."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from disn_amd.pipeline import _Comm, triangle_segments
+    comm = _Comm(dist)
+    comm.host = False
+    counts = [(0, 0, 0) if r in (1, world - 2) else (r + 1, 2 + r, 3 + r) for r in range(world)]   # two empty slabs
+    ncf = [min(c[0], c[2]) for c in counts]
+    seg = triangle_segments(counts, ncf)
+    nt = counts[rank][2]
+    tris = torch.full((nt, 3), rank, dtype=torch.int32)
+    if rank != 0:
+        comm.exchange([(tris[:ncf[rank]], 0), (tris[ncf[rank]:], 0)], [])
+    else:
+        gt = torch.full((sum(c[2] for c in counts), 3), -1, dtype=torch.int32)
+        recvs = []
+        for r in range(world):
+            cfo, efo = seg[r]
+            if r == 0:
+                gt[cfo:cfo + ncf[0]] = tris[:ncf[0]]
+                gt[efo:efo + nt - ncf[0]] = tris[ncf[0]:]
+            else:
+                recvs += [(gt[cfo:cfo + ncf[r]], r), (gt[efo:efo + counts[r][2] - ncf[r]], r)]
+        comm.exchange([], recvs)
+        want = [r for r in reversed(range(world)) for _ in range(ncf[r])] + \
+               [r for r in range(world) for _ in range(counts[r][2] - ncf[r])]
+        ok = gt[:, 0].tolist() == want
+        open(tmp, "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_exchange_with_empty_slabs(world, tmp_path):
+    port = 33500 + os.getpid() % 2000 + world
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_empty_exchange_worker, args=(world, port, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_seam_check():
+    from disn_amd.pipeline import seams_in_order
+    gt = torch.tensor([[0, 5, 6], [0, 7, 1], [2, 3, 4], [2, 3, 5], [9, 9, 9]], dtype=torch.int32)
+    assert seams_in_order(gt, [(0, 2), (2, 2), (4, 1)])
+    assert seams_in_order(gt, [(2, 2), (0, 2), (4, 0), (4, 1)])          # any listing order, empty pieces skipped
+    assert seams_in_order(gt, [(0, 5)]) and seams_in_order(gt, [])
+    bad = gt.clone()
+    bad[2] = torch.tensor([0, 6, 9])                                       # first row of the second piece below the seam
+    assert not seams_in_order(bad, [(0, 2), (2, 2), (4, 1)])
+    dup = gt.clone()
+    dup[2] = dup[1]                                                        # equal triangles across a seam never occur
+    assert not seams_in_order(dup, [(0, 2), (2, 2), (4, 1)])
