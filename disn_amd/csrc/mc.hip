@@ -17,6 +17,8 @@
 // Compile with -ffp-contract=off: App. B specifies separately rounded
 // products; the arithmetic intrinsics below make that explicit as well.
 #include <float.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 #include <mutex>
@@ -379,6 +381,215 @@ __global__ __launch_bounds__(BLK) void mc_classify(const float* __restrict__ sdf
   }
 }
 
+// ---- mc_classify_walk: the same outputs (info, per-tile counters, centres per layer) with every grid value
+// fetched about once and almost no arithmetic away from the surface.
+// mc_classify's linear tiles read a value from four places (its row, the row before, and both in the plane before),
+// which round-robin dispatch spreads over the XCDs (3.9x the grid in fabric traffic at sdf_res 1024), and spend
+// ~100 VALU instructions on every point.  Here a thread owns a column of 4 x 4 points (4 consecutive x, 4
+// consecutive rows) and walks L planes upwards: per step it loads the 5 x 5 values of the next plane above its
+// points (two planes ahead of their use, so two loads are in flight per thread), 1.25 x (L+1)/L of the grid in
+// total (the fifth value of a row is the next thread's first: the same cache line).  A step whose 50 values
+// (this plane and the one above) all lie on one side of the iso value, none of them within 2^-60 of it -- no sign
+// change, no product that could underflow (B.9) -- owns no vertex and no triangle: it is recognised with a
+// min / max over the new plane (the shift v - iso is monotonic in v) and only writes its 16 "nothing here"
+// entries.  The other steps -- the surface, a few lanes of a wave at a time -- are handed to the whole wave:
+// four such lanes' 4 x 4 points make 64 work items, each of which reads its corners again (cache hits) and takes
+// the per-point path of the specification (edge flags B.4 / B.9, corner code, sub-table lookup B.3).  Counters go
+// straight to the per-tile sums with global atomics (bsum and layer_centre start at zero): they fire only next
+// to the surface.
+constexpr int WROWS = 4;
+constexpr float WALK_TINY = 8.67361737988403547e-19f;   // 2^-60: products of larger values cannot underflow
+
+// raw values of plane k above the column (x0.., j0..); entries outside the grid copy `fill` (an existing value of
+// the column: neutral for the min / max test)
+__device__ __forceinline__ void walk_load_plane(const float* __restrict__ sdf, const Dims& d, int x0, int j0, int k, bool alive,
+                                                float fill, float (&v)[WROWS + 1][ITEMS + 1]) {
+  const bool fullx = x0 + ITEMS < d.nx;
+#pragma unroll
+  for (int r = 0; r <= WROWS; ++r) {
+    const int j = j0 + r;
+    if (!alive || k >= d.nz || j >= d.ny) {
+#pragma unroll
+      for (int t = 0; t <= ITEMS; ++t) v[r][t] = fill;
+      continue;
+    }
+    const float* row = sdf + (size_t)k * d.sxy + (size_t)j * d.nx + x0;
+    if (fullx) {
+      const float4u q = *(const float4u*)row;
+      v[r][0] = q[0]; v[r][1] = q[1]; v[r][2] = q[2]; v[r][3] = q[3];
+      v[r][ITEMS] = row[ITEMS];
+    } else {
+#pragma unroll
+      for (int t = 0; t <= ITEMS; ++t) v[r][t] = x0 + t < d.nx ? row[t] : fill;
+    }
+  }
+}
+__device__ __forceinline__ void walk_minmax(const float (&v)[WROWS + 1][ITEMS + 1], float& mn, float& mx) {
+  float a[WROWS + 1], b[WROWS + 1];
+#pragma unroll
+  for (int r = 0; r <= WROWS; ++r) {
+    a[r] = fminf(fminf(v[r][0], v[r][1]), fminf(fminf(v[r][2], v[r][3]), v[r][4]));
+    b[r] = fmaxf(fmaxf(v[r][0], v[r][1]), fmaxf(fmaxf(v[r][2], v[r][3]), v[r][4]));
+  }
+  mn = fminf(fminf(a[0], a[1]), fminf(fminf(a[2], a[3]), a[4]));
+  mx = fmaxf(fmaxf(b[0], b[1]), fmaxf(fmaxf(b[2], b[3]), b[4]));
+}
+
+// one grid point by the book (any position, boundary included): info entry and counters
+__device__ __forceinline__ void walk_point(const float* __restrict__ sdf, const Dims& d, int i, int j, int k,
+                                           uint16_t* __restrict__ info, unsigned* __restrict__ bsum,
+                                           unsigned* __restrict__ layer_centre) {
+  const unsigned p = (unsigned)k * d.sxy + (unsigned)j * d.nx + (unsigned)i;
+  const bool hx = i < d.nx - 1, hy = j < d.ny - 1, hz = k < d.nz - 1;
+  float c[8];
+  c[0] = cval(sdf, p, d.iso);
+  c[1] = hx ? cval(sdf, p + 1, d.iso) : 1.0f;
+  c[3] = hy ? cval(sdf, p + d.nx, d.iso) : 1.0f;
+  c[4] = hz ? cval(sdf, p + d.sxy, d.iso) : 1.0f;
+  if (hx && hy && hz) {
+    c[2] = cval(sdf, p + 1 + d.nx, d.iso);
+    c[5] = cval(sdf, p + d.sxy + 1, d.iso);
+    c[6] = cval(sdf, p + d.sxy + 1 + d.nx, d.iso);
+    c[7] = cval(sdf, p + d.sxy + d.nx, d.iso);
+  } else {
+    c[2] = c[5] = c[6] = c[7] = 1.0f;
+  }
+  unsigned code;
+  const unsigned fl = point_flags_code(sdf, d, i, j, k, c, hx, hy, hz, &code);
+  const unsigned sub = (code != 0 && code != 255) ? classify(c) : (unsigned)NOSUB;
+  info[p] = (unsigned short)(sub | (fl << 10));
+  const bool low = k < d.own0, owned = k >= d.own0 && k < d.own1;
+  unsigned* bs = bsum + (size_t)(p / TILE) * NCNT;
+  if (fl) {
+    const unsigned ne = __popc(fl);
+    atomicAdd(&bs[0], ne);
+    if (low) atomicAdd(&bs[3], ne);
+    if (owned) atomicAdd(&bs[4], ne);
+  }
+  if (owned && sub != NOSUB) {
+    const unsigned char* st = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub]];
+    atomicAdd(&bs[1], (unsigned)(st[0] / 3));
+    if (st[1]) {
+      atomicAdd(&bs[2], 1u);
+      atomicAdd(&layer_centre[k], 1u);
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLK) void mc_classify_walk(const float* __restrict__ sdf, Dims d, uint16_t* __restrict__ info,
+                                                         unsigned* __restrict__ bsum, unsigned* __restrict__ layer_centre,
+                                                         int nq, int ng, int L, FastDiv dnq, FastDiv dng, unsigned nthreads) {
+  const unsigned tid = blockIdx.x * BLK + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool valid = tid < nthreads;
+  int x0 = 0, j0 = 0, k0 = 0, k1 = 0;
+  if (valid) {
+    const unsigned t2 = fdiv(tid, dnq);
+    const unsigned ch = fdiv(t2, dng);
+    x0 = (int)(tid - t2 * (unsigned)nq) * ITEMS;
+    j0 = (int)(t2 - ch * (unsigned)ng) * WROWS;
+    k0 = (int)ch * L;
+    k1 = min(d.nz, k0 + L);
+  }
+  const float fill = sdf[valid ? (size_t)k0 * d.sxy + (size_t)j0 * d.nx + x0 : 0];
+  const bool fullx = x0 + ITEMS <= d.nx;   // all four points of a row exist
+  __shared__ unsigned queue[BLK / 64][128];   // per wave: surface points waiting for the long path
+  volatile unsigned* myq = queue[threadIdx.x >> 6];
+  unsigned qn = 0;                             // wave-uniform
+  float hi[WROWS + 1][ITEMS + 1], nn[WROWS + 1][ITEMS + 1];
+  float lo_min, lo_max;
+  walk_load_plane(sdf, d, x0, j0, k0, valid, fill, hi);
+  walk_minmax(hi, lo_min, lo_max);
+  walk_load_plane(sdf, d, x0, j0, k0 + 1, valid, fill, hi);
+  for (int s = 0; s < L; ++s) {   // every lane of the wave stays in the loop: the surface steps are worked on together
+    const int k = k0 + s;
+    const bool alive = valid && k < k1;
+    walk_load_plane(sdf, d, x0, j0, k + 2, alive && s + 1 < L, fill, nn);   // two planes ahead
+    float hi_min, hi_max;
+    walk_minmax(hi, hi_min, hi_max);
+    const float cmin = __fsub_rn(fminf(lo_min, hi_min), d.iso), cmax = __fsub_rn(fmaxf(lo_max, hi_max), d.iso);
+#ifdef WALK_FORCE_QUIET   // timing experiment only (wrong results)
+    const bool quiet = cmin > -3e38f;
+#else
+    const bool quiet = cmin > WALK_TINY || cmax < -WALK_TINY;
+#endif
+    if (alive && quiet) {
+      // 16 entries "no surface, no edge slot"; a row starts at any parity (nx is odd), so 4-byte stores only where aligned
+      const unsigned two = NOSUB | (NOSUB << 16);
+#pragma unroll
+      for (int r = 0; r < WROWS; ++r) {
+        if (j0 + r >= d.ny) break;
+        const unsigned prow = (unsigned)k * d.sxy + (unsigned)(j0 + r) * d.nx + (unsigned)x0;
+        if (fullx) {
+          if ((prow & 1u) == 0) {
+            *(unsigned*)(info + prow) = two;
+            *(unsigned*)(info + prow + 2) = two;
+          } else {
+            info[prow] = (unsigned short)NOSUB;
+            *(unsigned*)(info + prow + 1) = two;
+            info[prow + 3] = (unsigned short)NOSUB;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < ITEMS; ++t)
+            if (x0 + t < d.nx) info[prow + t] = (unsigned short)NOSUB;
+        }
+      }
+    }
+    unsigned long long need = __ballot(alive && !quiet);
+    while (need) {   // wave-uniform: four columns at a time, one of their 64 points per lane
+      int src[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        src[u] = need ? __ffsll((long long)need) - 1 : -1;
+        if (need) need &= need - 1;
+      }
+      const int grp = lane >> 4, pt = lane & 15;
+      const int from = grp == 0 ? src[0] : grp == 1 ? src[1] : grp == 2 ? src[2] : src[3];
+      const int sl = from < 0 ? 0 : from;
+      const int sx = __shfl(x0, sl, 64), sj = __shfl(j0, sl, 64), sk = __shfl(k, sl, 64);
+      const int i = sx + (pt & 3), j = sj + (pt >> 2);
+      // the point's own eight corners (those that exist) decide whether it is next to the surface at all
+      bool active = false;
+      unsigned p = 0;
+      if (from >= 0 && i < d.nx && j < d.ny) {
+        p = (unsigned)sk * d.sxy + (unsigned)j * d.nx + (unsigned)i;
+        const unsigned ox = i < d.nx - 1 ? 1u : 0u, oy = j < d.ny - 1 ? (unsigned)d.nx : 0u, oz = sk < d.nz - 1 ? d.sxy : 0u;
+        const float a0 = sdf[p], a1 = sdf[p + ox], a2 = sdf[p + oy], a3 = sdf[p + ox + oy];
+        const float b0 = sdf[p + oz], b1 = sdf[p + oz + ox], b2 = sdf[p + oz + oy], b3 = sdf[p + oz + ox + oy];
+        const float mn = fminf(fminf(fminf(a0, a1), fminf(a2, a3)), fminf(fminf(b0, b1), fminf(b2, b3)));
+        const float mx = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
+        active = !(__fsub_rn(mn, d.iso) > WALK_TINY || __fsub_rn(mx, d.iso) < -WALK_TINY);
+        if (!active) info[p] = (unsigned short)NOSUB;
+      }
+      // surface points collect in the wave's queue and take the long path 64 at a time
+      const unsigned long long act = __ballot(active);
+      if (active) myq[qn + __popcll(act & ((1ull << lane) - 1ull))] = p;
+      qn += __popcll(act);
+      if (qn >= 64) {
+        const unsigned pq = myq[lane];
+        const unsigned rest = lane < (int)(qn - 64) ? myq[64 + lane] : 0u;
+        int qi, qj, qk;
+        point_ijk(d, pq, qi, qj, qk);
+        walk_point(sdf, d, qi, qj, qk, info, bsum, layer_centre);
+        if (lane < (int)(qn - 64)) myq[lane] = rest;
+        qn -= 64;
+      }
+    }
+    lo_min = hi_min;
+    lo_max = hi_max;
+#pragma unroll
+    for (int r = 0; r <= WROWS; ++r)
+#pragma unroll
+      for (int t = 0; t <= ITEMS; ++t) hi[r][t] = nn[r][t];
+  }
+  if (lane < (int)qn) {   // what is left in the queue
+    int qi, qj, qk;
+    point_ijk(d, myq[lane], qi, qj, qk);
+    walk_point(sdf, d, qi, qj, qk, info, bsum, layer_centre);
+  }
+}
+
 // Two-level exclusive scan of the per-tile counters.  Level 1, one workgroup per chunk of SCAN_CHUNK
 // tiles: boff[b][0..2] = prefix of (E_all, T_own, C_own) inside the chunk, csum[chunk][0..4] = chunk sums.
 constexpr int SCAN_CHUNK = BLK * ITEMS;   // 1024 tiles
@@ -497,9 +708,10 @@ __device__ __forceinline__ void load_info4(const uint16_t* __restrict__ info, co
 
 // boff = prefix inside the chunk of SCAN_CHUNK tiles, coff = prefix over the chunks
 __global__ __launch_bounds__(BLK) void mc_vertices(const float* __restrict__ sdf, Dims d, const uint16_t* __restrict__ info,
-                                                    const unsigned* __restrict__ boff, const unsigned* __restrict__ coff,
-                                                    unsigned* __restrict__ vbase, EmitArgs a) {
+                                                    const unsigned* __restrict__ bsum, const unsigned* __restrict__ boff,
+                                                    const unsigned* __restrict__ coff, unsigned* __restrict__ vbase, EmitArgs a) {
   __shared__ unsigned lds[BLK / 64];
+  if (bsum[(size_t)blockIdx.x * NCNT + 0] == 0) return;   // no edge slot in this tile (most tiles): nothing to rank or emit
   const unsigned p0 = blockIdx.x * TILE + threadIdx.x * ITEMS;
   unsigned w[ITEMS], fl[ITEMS], ne = 0;
   load_info4(info, d, p0, w);
@@ -551,10 +763,11 @@ __global__ __launch_bounds__(BLK) void mc_vertices(const float* __restrict__ sdf
 }
 
 __global__ __launch_bounds__(BLK) void mc_triangles(const float* __restrict__ sdf, Dims d, const uint16_t* __restrict__ info,
-                                                     const unsigned* __restrict__ boff, const unsigned* __restrict__ coff,
-                                                     const unsigned* __restrict__ vbase,
+                                                     const unsigned* __restrict__ bsum, const unsigned* __restrict__ boff,
+                                                     const unsigned* __restrict__ coff, const unsigned* __restrict__ vbase,
                                                      const unsigned* __restrict__ layer_asc, EmitArgs a) {
   __shared__ unsigned lds[BLK / 64];
+  if (bsum[(size_t)blockIdx.x * NCNT + 1] == 0) return;   // no owned triangle (hence no centre vertex) in this tile
   const unsigned p0 = blockIdx.x * TILE + threadIdx.x * ITEMS;
   const unsigned own_lo = (unsigned)d.own0 * d.sxy, own_hi = (unsigned)d.own1 * d.sxy;   // owned layers as a point range
   unsigned w[ITEMS], sub4[ITEMS], packed = 0;
@@ -790,6 +1003,7 @@ __global__ void tri_copy_gated(const int* __restrict__ src, int* __restrict__ ds
 struct McState {
   DevBuf info, vbase, bsum, boff, csum, coff, layer, layer_asc, totals, sort_tmp, sort_hist;
   bool counted = false;
+  bool classify_linear = false;   // development switch (DISN_MC_CLASSIFY=linear): the round-2 kernel, for A/B runs
   const float* sdf = nullptr;
   Dims d{};
   int nz_global = 0;
@@ -807,7 +1021,11 @@ void disn_mc_state_free(DisnCtx* ctx) {
 }
 
 static McState* mc_state(DisnCtx* ctx) {
-  if (!ctx->mc) ctx->mc = new McState();
+  if (!ctx->mc) {
+    ctx->mc = new McState();
+    const char* e = getenv("DISN_MC_CLASSIFY");
+    ctx->mc->classify_linear = e && !strcmp(e, "linear");
+  }
   return ctx->mc;
 }
 
@@ -847,8 +1065,23 @@ extern "C" int disn_mc_count(DisnCtx* ctx, const float* sdf, const DisnMcGrid* g
   DISN_TRY(disn_ensure(ctx, m->layer_asc, (size_t)(g->nz + 2) * sizeof(unsigned)));
   DISN_TRY(disn_ensure(ctx, m->totals, NCNT * sizeof(unsigned long long)));
   DISN_HIP(ctx, hipMemsetAsync(m->layer.p, 0, (size_t)(g->nz + 1) * sizeof(unsigned), stream));
-  mc_classify<<<(nb + CLS_TILES - 1) / CLS_TILES, BLK, 0, stream>>>(sdf, d, (uint16_t*)m->info.p, (unsigned*)m->bsum.p, nb,
-                                                                    (unsigned*)m->layer.p);
+  if (m->classify_linear) {
+    mc_classify<<<(nb + CLS_TILES - 1) / CLS_TILES, BLK, 0, stream>>>(sdf, d, (uint16_t*)m->info.p, (unsigned*)m->bsum.p, nb,
+                                                                      (unsigned*)m->layer.p);
+  } else {
+    // columns of 4 x 4 points walking L planes; L: enough threads to fill the chip, at least 4 planes per walk
+    const int nq = (g->nx + ITEMS - 1) / ITEMS, ng = (g->ny + WROWS - 1) / WROWS;
+    const long long per_chunk = (long long)nq * ng, want_threads = 512 * 1024;
+    long long nc = (want_threads + per_chunk - 1) / per_chunk;
+    int L = (int)((g->nz + nc - 1) / nc);
+    if (L < 4) L = 4;
+    nc = (g->nz + L - 1) / L;
+    const long long nthreads = per_chunk * nc;
+    DISN_HIP(ctx, hipMemsetAsync(m->bsum.p, 0, (size_t)nb * NCNT * sizeof(unsigned), stream));
+    mc_classify_walk<<<(unsigned)((nthreads + BLK - 1) / BLK), BLK, 0, stream>>>(
+        sdf, d, (uint16_t*)m->info.p, (unsigned*)m->bsum.p, (unsigned*)m->layer.p, nq, ng, L, make_fastdiv((unsigned)nq),
+        make_fastdiv((unsigned)ng), (unsigned)nthreads);
+  }
   mc_scan_tiles<<<nchunk, BLK, 0, stream>>>((const unsigned*)m->bsum.p, nb, (unsigned*)m->boff.p, (unsigned*)m->csum.p);
   mc_scan<<<1, 1024, 0, stream>>>((const unsigned*)m->csum.p, nchunk, (unsigned*)m->coff.p,
                                   (unsigned long long*)m->totals.p, (const unsigned*)m->layer.p,
@@ -995,10 +1228,10 @@ extern "C" int disn_mc_emit(DisnCtx* ctx, const double* bbox, uint64_t centre_ba
   a.verts = verts;
   a.keys = (long long*)keys;
   a.tris = tris;
-  mc_vertices<<<m->nb, BLK, 0, stream>>>(m->sdf, d, (const uint16_t*)m->info.p, (const unsigned*)m->boff.p,
-                                         (const unsigned*)m->coff.p, (unsigned*)m->vbase.p, a);
-  mc_triangles<<<m->nb, BLK, 0, stream>>>(m->sdf, d, (const uint16_t*)m->info.p, (const unsigned*)m->boff.p,
-                                          (const unsigned*)m->coff.p, (const unsigned*)m->vbase.p,
+  mc_vertices<<<m->nb, BLK, 0, stream>>>(m->sdf, d, (const uint16_t*)m->info.p, (const unsigned*)m->bsum.p,
+                                         (const unsigned*)m->boff.p, (const unsigned*)m->coff.p, (unsigned*)m->vbase.p, a);
+  mc_triangles<<<m->nb, BLK, 0, stream>>>(m->sdf, d, (const uint16_t*)m->info.p, (const unsigned*)m->bsum.p,
+                                          (const unsigned*)m->boff.p, (const unsigned*)m->coff.p, (const unsigned*)m->vbase.p,
                                           (const unsigned*)m->layer_asc.p, a);
   DISN_HIP(ctx, hipGetLastError());
   if (sort) DISN_TRY(sort_tris(ctx, m, tris, nt, max_index, stream, false));
