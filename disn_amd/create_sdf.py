@@ -25,7 +25,9 @@ r, r+world, ...; there is no data-path collective.
 import argparse
 import glob
 import os
+import queue
 import sys
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -125,18 +127,46 @@ def read_list(lst_dir, cat_ids, view_num, seed=0):
     return out
 
 
-class BatchMesher:
-    """One GPU's share of the job: views in, OBJ files out."""
+class _Lane:
+    """One context + encoder (+ camera network) on its own HIP stream, fed by its own thread."""
 
-    def __init__(self, ctx, encoder, res, iso, out_root, cam=None, writers=4, store_dist=False, median_iso=False):
+    def __init__(self, ctx, encoder, cam):
         from .pipeline import MeshPipeline
+        self.ctx, self.enc, self.cam = ctx, encoder, cam
+        self.pipe = MeshPipeline(ctx)
+        self.stream = None
+        self.thread = None
+        self.queue = None
+
+
+class BatchMesher:
+    """One GPU's share of the job: views in, OBJ files out.
+
+    With `extra_lanes` (more (ctx, encoder, cam) triples on the same GPU, each with its own weights and per-image
+    buffers) views are dealt round-robin to one worker thread per lane, each on its own HIP stream: while one view's
+    decoder occupies the CUs, the other lane's encoder, coarse-iso launch, marching cubes and device->host copies
+    run in its shadow and its next decode is already queued -- the GPU never waits for the host.  This replaces the
+    reference's overlap of MC subprocesses with the next batch (reference demo/demo.py:291,338)."""
+
+    def __init__(self, ctx, encoder, res, iso, out_root, cam=None, writers=4, store_dist=False, median_iso=False,
+                 extra_lanes=()):
         self.ctx, self.enc, self.res, self.iso, self.root = ctx, encoder, res, iso, out_root
         self.cam = cam                    # (camera Vgg16Encoder, camera weights) or None
-        self.pipe = MeshPipeline(ctx)
+        self.lanes = [_Lane(ctx, encoder, cam)] + [_Lane(*l) for l in extra_lanes]
+        self.pipe = self.lanes[0].pipe
         self.pool = ThreadPoolExecutor(max_workers=writers)
         self.store_dist, self.median_iso = store_dist, median_iso
         self.pending = []
-        self.stats = []                   # (obj file, vertices, faces, gpu ms)
+        self.stats = []                   # (obj file, vertices, faces, gpu ms), in submission order after finish()
+        self._n = 0
+        self._lock = threading.Lock()
+        self._error = None
+        if len(self.lanes) > 1:
+            for lane in self.lanes:
+                lane.stream = torch.cuda.Stream(device=lane.ctx.device)
+                lane.queue = queue.Queue(maxsize=2)
+                lane.thread = threading.Thread(target=self._work, args=(lane,), daemon=True)
+                lane.thread.start()
 
     def _write(self, path, verts, tris, sdf, params):
         from . import api
@@ -146,35 +176,93 @@ class BatchMesher:
         api.write_obj(path, verts, tris)
         return path
 
-    def submit(self, view):
+    def _work(self, lane):
+        torch.cuda.set_device(lane.ctx.device)
+        with torch.cuda.stream(lane.stream):
+            while True:
+                item = lane.queue.get()
+                if item is None:
+                    return
+                try:
+                    if self._error is None:
+                        self._mesh(lane, *item)
+                except BaseException as e:     # surfaced by submit() / finish(): nothing fails silently
+                    self._error = e
+
+    def _mesh(self, lane, seq, view, path):
         from .pipeline import coarse_median_iso
         t0 = time.perf_counter()
-        gfeat, feats = self.enc(view["img"])
+        gfeat, feats = lane.enc(view["img"])
         trans_mat = view["trans_mat"]
-        if self.cam is not None:
+        if lane.cam is not None:
             from . import camera
-            emb, _ = self.cam[0](view["img"], feats=False)
-            trans_mat = camera.pred_trans_mat(emb, self.cam[1])[0].cpu().numpy()
+            emb, _ = lane.cam[0](view["img"], feats=False)
+            trans_mat = camera.pred_trans_mat(emb, lane.cam[1])[0].cpu().numpy()
         params = tuple(float(v) for v in view["sdf_params"])
         iso = self.iso
+        lane.ctx.set_image(feats, gfeat)
         if self.median_iso:
             # one coarse launch over the view's box (36 K points), not a second full grid
-            self.ctx.set_image(feats, gfeat)
-            iso = coarse_median_iso(self.ctx, trans_mat, params)
-        verts, tris = self.pipe.run(feats, gfeat, trans_mat, self.res, iso, params)
-        v, t = verts.cpu().numpy(), tris.cpu().numpy()        # synchronises
-        sdf = self.pipe.last_sdf.cpu().numpy() if self.store_dist else None
+            iso = coarse_median_iso(lane.ctx, trans_mat, params)
+        verts, tris = lane.pipe.run(feats, gfeat, trans_mat, self.res, iso, params, image_set=True)
+        v, t = verts.cpu().numpy(), tris.cpu().numpy()        # synchronises this lane's stream only
+        sdf = lane.pipe.last_sdf.cpu().numpy() if self.store_dist else None
         ms = (time.perf_counter() - t0) * 1e3
+        fut = self.pool.submit(self._write, path, v, t, sdf, params)
+        with self._lock:
+            self.pending.append(fut)
+            self.stats.append((seq, path, len(v), len(t), ms))
+
+    def submit(self, view):
+        if self._error is not None:
+            raise self._error
         path = obj_file_name(self.root, view["cat_id"], view["obj_nm"], view["view_id"])
-        self.pending.append(self.pool.submit(self._write, path, v, t, sdf, params))
-        self.stats.append((path, len(v), len(t), ms))
+        seq, self._n = self._n, self._n + 1
+        if len(self.lanes) == 1:
+            self._mesh(self.lanes[0], seq, view, path)
+        else:
+            self.lanes[seq % len(self.lanes)].queue.put((seq, view, path))   # blocks when that lane is two views behind
         return path
 
+    def drain(self):
+        """Wait until every submitted view has been meshed (the OBJ writers may still be running)."""
+        if len(self.lanes) > 1:
+            for lane in self.lanes:
+                lane.queue.put(None)
+            for lane in self.lanes:
+                lane.thread.join()
+            for lane in self.lanes:       # ready for more work
+                lane.thread = threading.Thread(target=self._work, args=(lane,), daemon=True)
+                lane.thread.start()
+        if self._error is not None:
+            raise self._error
+
     def finish(self):
+        if len(self.lanes) > 1:
+            for lane in self.lanes:
+                lane.queue.put(None)
+            for lane in self.lanes:
+                lane.thread.join()
+        if self._error is not None:
+            raise self._error
         for f in self.pending:
             f.result()                    # re-raises a writer's exception: nothing fails silently
         self.pool.shutdown()
-        return self.stats
+        return [st[1:] for st in sorted(self.stats)]
+
+
+def second_lane(ctx, decoder_weights, vgg_weights, cam_weights=None):
+    """Another (ctx, encoder, cam) on ctx's GPU with the same weights, for BatchMesher(extra_lanes=[...])."""
+    from . import api
+    from .encoder import Vgg16Encoder
+    c2 = api.Context(ctx.device.index or 0)
+    c2.set_weights(decoder_weights)
+    if not ctx.auto_decoder:
+        c2.set_decoder(ctx.decoder)
+    cam = None
+    if cam_weights is not None:
+        cam = (Vgg16Encoder(c2, cam_weights[0], slot=1), cam_weights[1])
+    return c2, Vgg16Encoder(c2, vgg_weights), cam
 
 
 def main(argv=None):
@@ -199,6 +287,8 @@ def main(argv=None):
     ap.add_argument("--random_init", action="store_true",
                     help="run on seeded random-init weights instead of checkpoints (no checkpoint is otherwise an error)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="views in flight per GPU, each with its own context and HIP stream (1 = strictly serial)")
     FLAGS = ap.parse_args(argv)
     if not FLAGS.img_feat_twostream:
         raise SystemExit("create_sdf: only the two-stream decoder (--img_feat_twostream) is built (SURVEY.md s2 row 3)")
@@ -219,24 +309,25 @@ def main(argv=None):
             raise SystemExit("create_sdf: no checkpoint under --log_dir %s (give --random_init to run on random "
                              "weights)" % FLAGS.log_dir)
         log("Model loaded in file: %s" % ckpt)
-        ctx.set_weights(tf_bundle.decoder_weights(ckpt))
-        enc = Vgg16Encoder(ctx, tf_bundle.vgg_weights(ckpt))
+        dec_w, vgg_w = tf_bundle.decoder_weights(ckpt), tf_bundle.vgg_weights(ckpt)
     else:
         log("create_sdf: --random_init -> seeded random-init weights (seed %d)" % FLAGS.seed)
-        ctx.set_weights(synth.decoder_weights(FLAGS.seed))
-        enc = Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed))
-    cam = None
+        dec_w, vgg_w = synth.decoder_weights(FLAGS.seed), synth.vgg_weights(FLAGS.seed)
+    ctx.set_weights(dec_w)
+    enc = Vgg16Encoder(ctx, vgg_w)
+    cam = cam_w = None
     if FLAGS.cam_est:
         from . import camera
         if random_init:
             log("create_sdf: --random_init -> seeded random-init camera network")
-            cam = (Vgg16Encoder(ctx, synth.vgg_weights(FLAGS.seed + 1), slot=1), camera.random_weights(FLAGS.seed))
+            cam_w = (synth.vgg_weights(FLAGS.seed + 1), camera.random_weights(FLAGS.seed))
         else:
             cam_ckpt = tf_bundle.latest_checkpoint(FLAGS.cam_log_dir)
             if cam_ckpt is None:
                 raise SystemExit("create_sdf: no checkpoint under --cam_log_dir %s (give --random_init to run on "
                                  "random weights)" % FLAGS.cam_log_dir)
-            cam = (Vgg16Encoder(ctx, tf_bundle.vgg_weights(cam_ckpt), slot=1), tf_bundle.camera_weights(cam_ckpt))
+            cam_w = (tf_bundle.vgg_weights(cam_ckpt), tf_bundle.camera_weights(cam_ckpt))
+        cam = (Vgg16Encoder(ctx, cam_w[0], slot=1), cam_w[1])
 
     if FLAGS.synthetic:
         views = synthetic_views(FLAGS.synthetic)
@@ -251,8 +342,9 @@ def main(argv=None):
 
     root = result_obj_path(FLAGS.log_dir, FLAGS.sdf_res, FLAGS.iso, FLAGS.cam_est)
     log("RESULT_OBJ_PATH: ", root)
+    extra = [second_lane(ctx, dec_w, vgg_w, cam_w) for _ in range(max(1, FLAGS.lanes) - 1)]
     mesher = BatchMesher(ctx, enc, FLAGS.sdf_res, FLAGS.iso, root, cam=cam, store_dist=FLAGS.store_dist,
-                         median_iso=FLAGS.median_iso or random_init)
+                         median_iso=FLAGS.median_iso or random_init, extra_lanes=extra)
     t0 = time.perf_counter()
     n = 0
     for idx, view in enumerate(views):
@@ -266,6 +358,8 @@ def main(argv=None):
     pts = n * (FLAGS.sdf_res + 1) ** 3
     print("create_sdf[rank %d/%d]: %d views, %.2f s, %.1f ms/view, %.1f M points/s, %d faces"
           % (rank, world, n, dt, dt / max(n, 1) * 1e3, pts / dt / 1e6, sum(s[2] for s in stats)), flush=True)
+    for lane in extra:
+        lane[0].close()
     ctx.close()
     return 0
 

@@ -254,7 +254,8 @@ extern "C" int disn_vgg_set_weights(DisnCtx* ctx, int slot, const DisnVggWeights
       c.pool_after = c.feat >= 0;
       // K split so that small maps still fill the chip; every split gets whole 16-k stages
       const int tiles = ((hw * hw + GT - 1) / GT) * ((cout + GT - 1) / GT), stages = c.kpad / GK;
-      int want = tiles >= cu ? 1 : (cu + tiles - 1) / tiles;
+      // (about three workgroups per CU: the kernel has no double buffering, co-resident workgroups hide its loads)
+      int want = tiles >= 3 * cu ? 1 : (3 * cu + tiles - 1) / tiles;
       if (want > stages) want = stages;
       c.per = (stages + want - 1) / want;
       c.nsplit = (stages + c.per - 1) / c.per;

@@ -133,9 +133,10 @@ class MeshPipeline:
             self.dist.broadcast(t, src=0)
         return feats, gfeat
 
-    def run(self, feats, gfeat, trans_mat, res, iso=0.0, sdf_params=(-1, -1, -1, 1, 1, 1), want_mesh=True):
+    def run(self, feats, gfeat, trans_mat, res, iso=0.0, sdf_params=(-1, -1, -1, 1, 1, 1), want_mesh=True, image_set=False):
         """feats: five device NHWC tensors (valid on rank 0, receive buffers elsewhere);
-        returns (verts[V,3] f64, tris[T,3] i32) device tensors on rank 0, (None, None) elsewhere."""
+        returns (verts[V,3] f64, tris[T,3] i32) device tensors on rank 0, (None, None) elsewhere.
+        image_set=True (single GPU): the caller has already done ctx.set_image(feats, gfeat) for this image."""
         ctx = self.ctx
         nz = res + 1
         if self.world > res:
@@ -144,7 +145,8 @@ class MeshPipeline:
         feats, gfeat = self._broadcast_features(feats, gfeat)
         ev = (lambda: self._mark()) if self.time_decode else (lambda: None)
         i0 = ev()
-        ctx.set_image(feats, gfeat)
+        if not (image_set and self.world == 1):
+            ctx.set_image(feats, gfeat)
         if self.world > 1 and self._agreed_weights != ctx.weights_version:
             # once per weight set (set_weights is called by every rank alike, so every rank gets here together):
             # each rank measures the same broadcast features with the same kernels, and rank 0's choice of decoder

@@ -73,3 +73,33 @@ def test_batch_mesher_matches_oracle_on_a_non_unit_box(ctx, tmp_path):
     v, f = _read_obj(path)
     assert np.array_equal(f, want["tris"])
     assert float(np.abs(v - want["verts"]).max()) < 1e-5 * max(1.0, float(np.abs(want["verts"]).max()))
+
+
+def test_two_lanes_write_the_same_files_as_one(ctx, tmp_path):
+    """BatchMesher with a second context / HIP stream / worker thread on the same GPU (views in flight overlap):
+    byte-identical OBJ files and the stats in submission order; a failing view surfaces at finish()."""
+    from disn_amd import create_sdf, synth
+    from disn_amd.encoder import Vgg16Encoder
+    wdec, wvgg = synth.decoder_weights(seed=5), synth.vgg_weights(seed=5)
+    ctx.set_weights(wdec)
+    enc = Vgg16Encoder(ctx, wvgg)
+    views = list(create_sdf.synthetic_views(7))
+    one = create_sdf.BatchMesher(ctx, enc, 40, 0.0, str(tmp_path / "one"), median_iso=True)
+    paths1 = [one.submit(v) for v in views]
+    stats1 = one.finish()
+    lane2 = create_sdf.second_lane(ctx, wdec, wvgg)
+    two = create_sdf.BatchMesher(ctx, enc, 40, 0.0, str(tmp_path / "two"), median_iso=True, extra_lanes=[lane2])
+    paths2 = [two.submit(v) for v in views[:4]]
+    two.drain()                                    # usable again after a drain
+    paths2 += [two.submit(v) for v in views[4:]]
+    stats2 = two.finish()
+    assert [s[0] for s in stats2] == paths2 and len(stats2) == 7
+    for a, b, s1, s2 in zip(paths1, paths2, stats1, stats2):
+        assert os.path.basename(a) == os.path.basename(b) and s1[1:3] == s2[1:3] and s1[2] > 500
+        assert open(a, "rb").read() == open(b, "rb").read()
+    bad = create_sdf.BatchMesher(ctx, enc, 40, 0.0, str(tmp_path / "bad"), extra_lanes=[lane2])
+    broken = dict(views[0], img=np.zeros((137, 137), np.float32))     # not HxWx3
+    bad.submit(broken)
+    with pytest.raises(Exception):
+        bad.finish()
+    lane2[0].close()
