@@ -453,9 +453,30 @@ struct Pipe {
       dma_range<A + 1, B>();
     }
   }
-  // middle of stage g: stage g+1 must be in LDS for everyone; slot of g-1 is free afterwards
+  // The mixed-precision kernels move the same bytes as eight 1 KiB pieces per wave and stage (J = 0..7; voff = lane * 16
+  // there): their K=64 MFMAs have 64-cycle shadows, which a 1 KiB piece fits, and a quarter of the issue slots is
+  // spent on the refill (tools/group_cost.hip, modes 2 / 4).
+  template <int J>
+  __device__ __forceinline__ void dma4_sub() const {
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2"
+                 :
+                 : "v"(voff), "s"(J >= 4 ? dma_src_hi : dma_src), "i"((J & 3) * 1024)
+                 : "memory");
+  }
+  template <int A, int B>
+  __device__ __forceinline__ void dma4_range() const {
+    if constexpr (A < B) {
+      dma4_sub<A>();
+      dma4_range<A + 1, B>();
+    }
+  }
+  // middle of stage g: stage g+1 must be in LDS for everyone; slot of g-1 is free afterwards.  PIECES = LDS-DMA
+  // instructions per wave and stage (32 of 256 B or 8 of 1 KiB)
+  template <int PIECES>
   __device__ __forceinline__ void mid_sync() {
-    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // all but the 32 sub-pieces of stage g+2
+    static_assert(PIECES == 32 || PIECES == 8, "piece count");
+    if constexpr (PIECES == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // all but the pieces of stage g+2
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // no tail special case: past the end the refill just re-reads the (wrapping) stream into a slot
@@ -521,7 +542,7 @@ __device__ __forceinline__ void pair_step(Pipe& pipe, Frags& fr, floatx16& acc, 
   SCHED_FENCE();
   mfma1<AGPR, false>(acc, fr.hi[c], xhi);
   SCHED_FENCE();
-  if constexpr (P == 7) pipe.mid_sync();
+  if constexpr (P == 7) pipe.template mid_sync<32>();
   extra(gap<2>{});
   SCHED_FENCE();
   if constexpr (P == STAGE_PAIRS - 1) pipe.advance();
@@ -939,18 +960,13 @@ __device__ __forceinline__ void unit_read(Pipe& pipe, Ring8& rg) {
   ring_put<U & 7>(rg, src[0]);
   SCHED_FENCE();
 }
-// the pieces of a stage must be issued in ascending order: M0 moves to the second half after piece 15
-template <int U>
-__device__ __forceinline__ void unit_dma(Pipe& pipe) {
-  constexpr int J = (U + 16) & 31;
-  pipe.template dma_sub<J>();
-  if constexpr (J == 15) pipe.dma_hi();
+// LDS-DMA piece Q (0..7, 1 KiB per wave) of the refill period; the pieces of a stage must be issued in ascending order
+// from the middle of the stage on (4, 5, 6, 7 | rendezvous | 0, 1, 2, 3): M0 moves to the second half after piece 3
+template <int Q>
+__device__ __forceinline__ void piece_dma(Pipe& pipe) {
+  pipe.template dma4_sub<Q>();
+  if constexpr (Q == 3) pipe.dma_hi();
   SCHED_FENCE();
-}
-template <int U>
-__device__ __forceinline__ void unit_refill(Pipe& pipe, Ring8& rg) {
-  unit_read<U>(pipe, rg);
-  unit_dma<U>(pipe);
 }
 
 template <bool AGPR, bool LEAD>
@@ -1006,37 +1022,40 @@ template <int G, bool AGPR, class Acc, class Extra>
 __device__ __forceinline__ void group_step_x(Pipe& pipe, Ring8& rg, Acc& acc, const XG& x, const intx8& xl8,
                                              const Scales& sc, Extra extra) {
   constexpr int U = 8 * G;
+  constexpr int Q = (2 * G + 4) & 7;   // this group's two 1 KiB refill pieces go into the shadows of the K=64 MFMAs
   mfma_f16<AGPR, true>(acc, rg.f[0], xg_hi<0>(x));
   SCHED_FENCE();
-  unit_refill<U + 0>(pipe, rg);
+  unit_read<U + 0>(pipe, rg);
   extra(gap<0>{});
   SCHED_FENCE();
   mfma_f16<AGPR, false>(acc, rg.f[1], xg_hi<1>(x));
   SCHED_FENCE();
-  unit_refill<U + 1>(pipe, rg);
+  unit_read<U + 1>(pipe, rg);
   extra(gap<1>{});
   SCHED_FENCE();
   mfma_f16<AGPR, false>(acc, rg.f[2], xg_hi<2>(x));
   SCHED_FENCE();
-  unit_refill<U + 2>(pipe, rg);
+  unit_read<U + 2>(pipe, rg);
   extra(gap<2>{});
   SCHED_FENCE();
   mfma_f16<AGPR, false>(acc, rg.f[3], xg_hi<3>(x));
   SCHED_FENCE();
-  unit_refill<U + 3>(pipe, rg);
+  unit_read<U + 3>(pipe, rg);
   extra(gap<3>{});
   SCHED_FENCE();
   mfma_fp8<AGPR>(acc, rg.e[0], xg_x8(x), sc.w, sc.xl);
   SCHED_FENCE();
-  unit_refill<U + 4>(pipe, rg);
-  unit_refill<U + 5>(pipe, rg);
+  unit_read<U + 4>(pipe, rg);
+  unit_read<U + 5>(pipe, rg);
+  piece_dma<Q>(pipe);
   extra(gap<4>{});
   SCHED_FENCE();
   mfma_fp8<AGPR>(acc, rg.e[1], xl8, sc.w, sc.xl);
   SCHED_FENCE();
-  unit_refill<U + 6>(pipe, rg);
-  unit_refill<U + 7>(pipe, rg);
-  if constexpr (G == 1) pipe.mid_sync();
+  unit_read<U + 6>(pipe, rg);
+  unit_read<U + 7>(pipe, rg);
+  piece_dma<Q + 1>(pipe);
+  if constexpr (G == 1) pipe.template mid_sync<8>();
   extra(gap<5>{});
   SCHED_FENCE();
   if constexpr (G == 3) pipe.advance();
@@ -1052,18 +1071,17 @@ __device__ __forceinline__ void pair_step8(Pipe& pipe, Ring8& rg, floatx16& acc,
   mfma1<AGPR, true>(acc, wlo, xhi);
   SCHED_FENCE();
   unit_read<U + 1>(pipe, rg);
-  unit_dma<U>(pipe);
   extra(gap<0>{});
   SCHED_FENCE();
   mfma1<AGPR, false>(acc, whi, xlo);
   SCHED_FENCE();
-  unit_dma<U + 1>(pipe);
+  if constexpr (P & 1) piece_dma<((P >> 1) + 4) & 7>(pipe);   // one 1 KiB piece per two pair steps
   extra(gap<1>{});
   SCHED_FENCE();
   mfma1<AGPR, false>(acc, whi, xhi);
   SCHED_FENCE();
   unit_read<U>(pipe, rg);
-  if constexpr (P == 7) pipe.mid_sync();
+  if constexpr (P == 7) pipe.template mid_sync<8>();
   extra(gap<2>{});
   SCHED_FENCE();
   if constexpr (P == 15) pipe.advance();
@@ -1355,9 +1373,9 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
   // half_of() = lane >> 5, recomputed from the DMA offset register at every use: addresses derived from a long-lived copy
   // cost registers that this kernel does not have
   auto half_of = [&]() {
-    unsigned vo = pipe.voff;
+    unsigned vo = pipe.voff;   // lane * 16 in this kernel
     asm volatile("" : "+v"(vo));
-    return (int)(vo >> 7);
+    return (int)(vo >> 9);
   };
   // fold2/conv1 accumulators: bias (+ image term), exactly as in the bf16 kernel
   floatx16 acc4[16];
@@ -1591,11 +1609,11 @@ __global__ __launch_bounds__(256, 1) void sdf_decode_mx(DecodeArgs a) {
   pipe.g = 0;
   pipe.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   pipe.lane = threadIdx.x & 63;
-  pipe.voff = pipe.lane * 4;
-  pipe.dma_setup(0); pipe.dma_range<0, 16>(); pipe.dma_hi(); pipe.dma_range<16, 32>();
-  pipe.dma_setup(1); pipe.dma_range<0, 16>(); pipe.dma_hi(); pipe.dma_range<16, 32>();
-  pipe.dma_setup(2); pipe.dma_range<0, 16>(); pipe.dma_hi();   // second half: units 0..15 of stage 0
-  asm volatile("s_waitcnt vmcnt(48)" ::: "memory");   // stage 0 landed
+  pipe.voff = pipe.lane * 16;   // 1 KiB LDS-DMA pieces: 16 bytes per lane
+  pipe.dma_setup(0); pipe.dma4_range<0, 4>(); pipe.dma_hi(); pipe.dma4_range<4, 8>();
+  pipe.dma_setup(1); pipe.dma4_range<0, 4>(); pipe.dma_hi(); pipe.dma4_range<4, 8>();
+  pipe.dma_setup(2); pipe.dma4_range<0, 4>(); pipe.dma_hi();   // second half: groups 0, 1 of stage 0
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // stage 0 landed
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   pipe.cur = pipe.slot_ptr(0);
