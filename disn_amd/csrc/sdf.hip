@@ -951,15 +951,19 @@ __device__ __forceinline__ intx4 ring_get(const Ring8& rg) {
   }
 }
 
-// stage unit U (slot U & 7) has just been consumed: refill its slot with unit U + 8 and issue the LDS-DMA
-// piece that belongs to U (one 256 B piece per unit; the refill period runs from the middle of one stage to
-// the middle of the next, as in the bf16 kernel)
+// stage unit U (slot U & 7) has just been consumed: refill its slot with unit U + 8
 template <int U>
 __device__ __forceinline__ void unit_read(Pipe& pipe, Ring8& rg) {
   const uint4* src = (U + 8 < UNITS_PER_STAGE) ? pipe.cur + (U + 8) * 64 : pipe.nxt + (U + 8 - UNITS_PER_STAGE) * 64;
   ring_put<U & 7>(rg, src[0]);
   SCHED_FENCE();
 }
+// shadows (0..5) of a group step that carry its two refill pieces (first <= second: the pieces are issued in order)
+#ifndef MX_DMA_GAPS
+#define MX_DMA_GAPS 4, 5
+#endif
+constexpr int MX_DMA_GAP[2] = {MX_DMA_GAPS};
+static_assert(MX_DMA_GAP[0] <= MX_DMA_GAP[1] && MX_DMA_GAP[1] <= 5, "refill pieces in ascending order");
 // LDS-DMA piece Q (0..7, 1 KiB per wave) of the refill period; the pieces of a stage must be issued in ascending order
 // from the middle of the stage on (4, 5, 6, 7 | rendezvous | 0, 1, 2, 3): M0 moves to the second half after piece 3
 template <int Q>
@@ -1022,39 +1026,49 @@ template <int G, bool AGPR, class Acc, class Extra>
 __device__ __forceinline__ void group_step_x(Pipe& pipe, Ring8& rg, Acc& acc, const XG& x, const intx8& xl8,
                                              const Scales& sc, Extra extra) {
   constexpr int U = 8 * G;
-  constexpr int Q = (2 * G + 4) & 7;   // this group's two 1 KiB refill pieces go into the shadows of the K=64 MFMAs
+  constexpr int Q = (2 * G + 4) & 7;   // this group's two 1 KiB refill pieces: by default in the shadows of the K=64 MFMAs
   mfma_f16<AGPR, true>(acc, rg.f[0], xg_hi<0>(x));
   SCHED_FENCE();
   unit_read<U + 0>(pipe, rg);
+  if constexpr (MX_DMA_GAP[0] == 0) piece_dma<Q>(pipe);
+  if constexpr (MX_DMA_GAP[1] == 0) piece_dma<Q + 1>(pipe);
   extra(gap<0>{});
   SCHED_FENCE();
   mfma_f16<AGPR, false>(acc, rg.f[1], xg_hi<1>(x));
   SCHED_FENCE();
   unit_read<U + 1>(pipe, rg);
+  if constexpr (MX_DMA_GAP[0] == 1) piece_dma<Q>(pipe);
+  if constexpr (MX_DMA_GAP[1] == 1) piece_dma<Q + 1>(pipe);
   extra(gap<1>{});
   SCHED_FENCE();
   mfma_f16<AGPR, false>(acc, rg.f[2], xg_hi<2>(x));
   SCHED_FENCE();
   unit_read<U + 2>(pipe, rg);
+  if constexpr (MX_DMA_GAP[0] == 2) piece_dma<Q>(pipe);
+  if constexpr (MX_DMA_GAP[1] == 2) piece_dma<Q + 1>(pipe);
   extra(gap<2>{});
   SCHED_FENCE();
   mfma_f16<AGPR, false>(acc, rg.f[3], xg_hi<3>(x));
   SCHED_FENCE();
   unit_read<U + 3>(pipe, rg);
+  if constexpr (MX_DMA_GAP[0] == 3) piece_dma<Q>(pipe);
+  if constexpr (MX_DMA_GAP[1] == 3) piece_dma<Q + 1>(pipe);
   extra(gap<3>{});
   SCHED_FENCE();
   mfma_fp8<AGPR>(acc, rg.e[0], xg_x8(x), sc.w, sc.xl);
   SCHED_FENCE();
   unit_read<U + 4>(pipe, rg);
   unit_read<U + 5>(pipe, rg);
-  piece_dma<Q>(pipe);
+  if constexpr (MX_DMA_GAP[0] == 4) piece_dma<Q>(pipe);
+  if constexpr (MX_DMA_GAP[1] == 4) piece_dma<Q + 1>(pipe);
   extra(gap<4>{});
   SCHED_FENCE();
   mfma_fp8<AGPR>(acc, rg.e[1], xl8, sc.w, sc.xl);
   SCHED_FENCE();
   unit_read<U + 6>(pipe, rg);
   unit_read<U + 7>(pipe, rg);
-  piece_dma<Q + 1>(pipe);
+  if constexpr (MX_DMA_GAP[0] == 5) piece_dma<Q>(pipe);
+  if constexpr (MX_DMA_GAP[1] == 5) piece_dma<Q + 1>(pipe);
   if constexpr (G == 1) pipe.template mid_sync<8>();
   extra(gap<5>{});
   SCHED_FENCE();

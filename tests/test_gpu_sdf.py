@@ -300,3 +300,56 @@ def test_autotune_catches_activations_beyond_fp8_range(ctx):
         print("chose", ctx.decoder)
         assert float(np.abs(got - want64).max()) <= TOL_SDF and e[ctx.decoder] * 5.0 <= 1e-4
     ctx.set_decoder("auto")
+
+
+def test_selfcheck_and_autotune_argument_and_state_errors(ctx, model):
+    from disn_amd.api import Context, DisnError
+    c = Context(0)
+    with pytest.raises(DisnError, match="set_weights"):
+        c.selfcheck(net.GT_TRANS_MAT)                       # no weights / image yet
+    with pytest.raises(DisnError, match="set_weights"):
+        c.autotune(net.GT_TRANS_MAT)
+    c.close()
+    maps, gf, w = model
+    ctx.set_weights(w)
+    ctx.set_image(maps, gf)
+    for n in (0, -5, 70000):
+        with pytest.raises(DisnError, match="n_points"):
+            ctx.selfcheck(net.GT_TRANS_MAT, n=n)
+    with pytest.raises(DisnError, match="margin"):
+        ctx.autotune(net.GT_TRANS_MAT, margin=0.5)
+    e1, m1 = ctx.selfcheck(net.GT_TRANS_MAT, n=1)           # a single sample point works
+    e2, m2 = ctx.selfcheck(net.GT_TRANS_MAT, n=4096)
+    e3, m3 = ctx.selfcheck(net.GT_TRANS_MAT, n=4096)
+    assert (e2, m2) == (e3, m3) and 0 <= e1 <= 1e-4 and 0 < e2 <= 1e-4 and m2 >= m1 > 0      # deterministic
+    # a non-unit box moves the sample points with it
+    e4, m4 = ctx.selfcheck(net.GT_TRANS_MAT, sdf_params=(-0.5, -0.4, -0.3, 0.2, 0.3, 0.4))
+    assert (e4, m4) != (e2, m2) and e4 <= 1e-4
+    # weights beyond the fp16 range: the mixed streams are not packed, bf16x3 still runs, auto ends there
+    w2 = dict(w)
+    w2["g_f1c3_w"] = w["g_f1c3_w"].copy()
+    w2["g_f1c3_w"][0, 0] = 1e5
+    ctx.set_decoder("auto")
+    ctx.set_weights(w2)
+    ctx.set_image(maps, gf)
+    for name in ("mixed", "mixed4"):
+        ctx.set_decoder(name)
+        with pytest.raises(DisnError, match="fp16 range"):
+            ctx.sdf_grid(net.GT_TRANS_MAT, 4)
+    ctx.set_decoder("bf16x3")
+    assert torch.isfinite(ctx.sdf_grid(net.GT_TRANS_MAT, 4)).all()
+    ctx.set_decoder("auto")
+    try:
+        ctx.sdf_grid(net.GT_TRANS_MAT, 4)
+        assert ctx.decoder == "bf16x3" and ctx.decoder_report["errors"]["mixed4"] is None
+    except DisnError as ex:                                   # or no arithmetic keeps the margin with such a weight
+        assert "no decoder arithmetic" in str(ex)
+    w3 = dict(w)
+    w3["l_f2c2_b"] = w["l_f2c2_b"].copy()
+    w3["l_f2c2_b"][3] = np.nan
+    with pytest.raises(DisnError, match="non-finite"):
+        ctx.set_weights(w3)
+    with pytest.raises(DisnError):
+        ctx.sdf_grid(net.GT_TRANS_MAT, 4)                     # a failed set_weights leaves no usable weights
+    ctx.set_weights(w)
+    ctx.set_image(maps, gf)

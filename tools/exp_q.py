@@ -9,7 +9,7 @@ os.makedirs(OUT, exist_ok=True)
 procs = []
 for n in sys.argv[1:]:
     kind, digits = n.split("_")
-    macro = {"mx5": "MX5_CVT_Q", "mx": "MX_CVT_Q"}[kind]
+    macro = {"mx5": "MX5_CVT_Q", "mx": "MX_CVT_Q", "dma": "MX_DMA_GAPS"}[kind]
     d = os.path.join("/tmp", "exp_q", n)
     os.makedirs(d, exist_ok=True)
     objs = " ".join(os.path.join(CSRC, o) for o in ("abi.o", "hostio.o", "mc.o", "vgg.o"))
