@@ -297,10 +297,10 @@ struct DecodeArgs {
   long long ntiles;         // tiles of 128 points
   // grid mode: the "core" [0,ic) x [0,jc) x [0,kc) (multiples of 8, 4, 4) is cut into bricks of 8 x 4 x 4 points,
   // one tile each; bricks are ordered in super-bricks of 2^sbi x 2^sbj x 2^sbk bricks; the rest of the slab
-  // (three boxes r1, r2, r3) is enumerated linearly after the core tiles
+  // follows wave by wave (grid_point: r1 patches of the planes k >= kc, r2 runs of the rows j >= jc, r3 runs of the columns i >= ic)
   int n1, nk, ic, jc, kc, sbi, sbj, sbk, nsi, nsj;
   long long core_tiles;
-  unsigned r1, r2, r3;      // points in the remainder boxes k >= kc, (k < kc, j >= jc), (k < kc, j < jc, i >= ic)
+  unsigned r1, r2, r3;      // waves of the three remainder regions
   double lo[3], hi[3], step[3];
   int scale_out;            // 1: out = float(double(pred)/10)  (reference demo/demo.py:335,351)
   float* out;
@@ -345,22 +345,32 @@ __device__ __forceinline__ bool grid_point(const Geom* g, unsigned t, int wave, 
     k = (int)(4u * ((sk << sbk) + lk)) + wave;
     return true;
   }
-  const unsigned n1 = (unsigned)g->n1, ic = g->ic, jc = g->jc, kc = g->kc, wj = n1 - jc, wi = n1 - ic;
-  const unsigned r1 = g->r1, r2 = g->r2, total = r1 + r2 + g->r3;
-  unsigned r = (t - core) * 128u + (unsigned)wave * 32u + (unsigned)l32;
-  const bool valid = r < total;
-  if (!valid) r = total - 1u;
-  if (r < r1) {                         // whole planes k >= kc
-    const unsigned plane = n1 * n1, kk = r / plane, rem = r - kk * plane, jj = rem / n1;
-    k = (int)(kc + kk); j = (int)jj; i = (int)(rem - jj * n1);
-  } else if (r - r1 < r2) {             // k < kc, j >= jc
-    r -= r1;
-    const unsigned slab = wj * n1, kk = r / slab, rem = r - kk * slab, jj = rem / n1;
-    k = (int)kk; j = (int)(jc + jj); i = (int)(rem - jj * n1);
-  } else {                              // k < kc, j < jc, i >= ic
-    r -= r1 + r2;
-    const unsigned slab = jc * wi, kk = r / slab, rem = r - kk * slab, jj = rem / wi;
-    k = (int)kk; j = (int)jj; i = (int)(ic + rem - jj * wi);
+  // The rest of the slab, one wave at a time, in an enumeration under which a grid point shares its wave with the same
+  // 31 others whatever the slab (so that its value does not depend on how the grid was cut: the image term's arithmetic
+  // follows the wave's pixel rectangle, blend_mfma):
+  //   B  planes k >= kc, (i < ic, j < jc): the same 8 x 4 patches as in the bricks, patch by patch;
+  //   C  rows j >= jc of every plane: runs of 32 consecutive i;      D  columns i >= ic (j < jc): runs of 32 consecutive j.
+  // Lanes beyond the end of a run repeat its last point and are not stored.
+  const unsigned n1 = (unsigned)g->n1, ic = g->ic, jc = g->jc, kc = g->kc;
+  const unsigned wb = g->r1, wc = g->r2, total = wb + wc + g->r3;
+  unsigned q = (t - core) * 4u + (unsigned)wave;
+  bool valid = q < total;
+  if (!valid) q = total - 1u;
+  if (q < wb) {
+    const unsigned pi_n = ic >> 3, ppp = pi_n * (jc >> 2), kk = q / ppp, rem = q - kk * ppp, pj = rem / pi_n;
+    k = (int)(kc + kk); j = (int)(4u * pj) + (l32 >> 3); i = (int)(8u * (rem - pj * pi_n)) + (l32 & 7);
+  } else if (q - wb < wc) {
+    q -= wb;
+    const unsigned nseg = (n1 + 31u) >> 5, per_k = (n1 - jc) * nseg, kk = q / per_k, rem = q - kk * per_k, jj = rem / nseg;
+    const unsigned ii = 32u * (rem - jj * nseg) + (unsigned)l32;
+    valid = valid && ii < n1;
+    k = (int)kk; j = (int)(jc + jj); i = (int)min(ii, n1 - 1u);
+  } else {
+    q -= wb + wc;
+    const unsigned nseg = (jc + 31u) >> 5, per_k = (n1 - ic) * nseg, kk = q / per_k, rem = q - kk * per_k, ii = rem / nseg;
+    const unsigned jj = 32u * (rem - ii * nseg) + (unsigned)l32;
+    valid = valid && jj < jc;
+    k = (int)kk; i = (int)(ic + ii); j = (int)min(jj, jc - 1u);
   }
   return valid;
 }
@@ -1379,6 +1389,131 @@ __device__ __forceinline__ void l3_stage_mx(Pipe& pipe, Ring8& rg, intx16& acc3,
   });
 }
 
+// ---- image term of fold2/conv1 as a matrix product (local stream of the mixed kernels) ----------------------------
+// A wave's 32 points are an 8 x 4 patch of one grid plane, and their projections fall into a small rectangle of
+// pixels (4 x 4 on average at sdf_res 256).  Instead of gathering the four corner rows of every point (256 load
+// instructions per wave that each touch 64 different cache lines: ~28 cycles apiece on the address path), the blend is
+// written as  acc[512 features x 32 points] = Pmap^T[features x pixels] . S[pixels x points]  with S the sparse matrix of
+// corner weights (<= 4 non-zeros per column), in chunks of 4 x 4 pixels = one K=16 bf16 MFMA step: lane (r, h) loads
+// Pmap[pixel 8h + j][32 nb + r] for j = 0..7 -- 128 contiguous bytes per half wave -- which IS the A-operand layout,
+// splits the eight values into bf16 hi + lo, and three products (lo.hi, hi.lo, hi.hi; fp32 accumulate, ~2^-17 relative,
+// as in the bf16 triple) land in the accumulator block.  Pixel rows beyond the image carry weight 0 and are read from
+// the zeroed tail of the Pmap buffer (PMAP_ROWS).  Waves whose rectangle needs more than BLEND_MAX_CHUNKS chunks
+// (scattered points, very coarse grids) take the gather instead.
+#ifndef BLEND_MAX_CHUNKS
+#define BLEND_MAX_CHUNKS 12
+#endif
+constexpr int PMAP_ROWS = (IMG + 4) * IMG + 8;   // pixel rows of the Pmap buffer incl. the zeroed tail
+__device__ __forceinline__ void split_bf16x8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  intx4 h, l;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int hp = cvt_pk_bf16(v[2 * q], v[2 * q + 1]);
+    const float r0 = __fsub_rn(v[2 * q], __int_as_float(hp << 16));
+    const float r1 = __fsub_rn(v[2 * q + 1], __int_as_float(hp & (int)0xffff0000));
+    h[q] = hp;
+    l[q] = cvt_pk_bf16(r0, r1);
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+// The split of one block's eight values (four pairs) as 20 single VALU ops in stage-major order -- hi pairs (RNE), their
+// two expansions, the exact packed subtraction, lo pairs -- so that neighbours in the instruction stream are independent
+// and a third of them fits the shadow of each of the previous block's three MFMAs.
+struct BlendSplit {
+  floatx2 e[4], r[4];
+  intx4 hi, lo;
+};
+template <int OP>
+__device__ __forceinline__ void blend_split_op(const floatx2 (&v)[4], BlendSplit& st) {
+  constexpr int stage = OP >> 2, q = OP & 3;
+  if constexpr (stage == 0) st.hi[q] = cvt_pk_bf16(v[q][0], v[q][1]);
+  else if constexpr (stage == 1) st.e[q][0] = __int_as_float(st.hi[q] << 16);
+  else if constexpr (stage == 2) st.e[q][1] = __int_as_float(st.hi[q] & (int)0xffff0000);
+  else if constexpr (stage == 3) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(st.r[q]) : "v"(v[q]), "v"(st.e[q]));
+  else st.lo[q] = cvt_pk_bf16(st.r[q][0], st.r[q][1]);
+}
+template <int N0, int N1>
+__device__ __forceinline__ void blend_split_ops(const floatx2 (&v)[4], BlendSplit& st) {
+  static_for<N1 - N0>([&](auto ic) { blend_split_op<N0 + decltype(ic)::value>(v, st); });
+}
+__device__ __forceinline__ void blend_mfma(floatx16 (&acc4)[16], const float* __restrict__ pmap, const Corners& cn,
+                                           int ifx, int ify, int x0, int y0, int ncx, int nchunks, int lane) {
+  const int l32 = lane & 31, hl = lane >> 5;
+  floatx2 t[16][4];   // t[block][pair]: the lane's eight pixels of the chunk, feature 32 block + l32
+  // byte offsets of the eight pixels from the chunk's first (rows are IMG pixels apart, pixels 2 KiB)
+  // 32-bit byte offsets from the (uniform) map base: the map is 38 MB
+  auto load_block = [&](floatx2 (&dst)[4], unsigned src, int nb4, int j0, int j1) {
+#pragma unroll
+    for (int j = j0; j < j1; ++j)
+      dst[j >> 1][j & 1] = *(const float*)((const char*)pmap + (src + (unsigned)(((j >> 2) * IMG + (j & 3)) * 2048 + 128 * nb4)));
+  };
+  auto chunk_src = [&](int cx, int cy) {
+    return (unsigned)(((y0 + 4 * cy + 2 * hl) * IMG + x0 + 4 * cx) * 2048 + 4 * l32);
+  };
+  {
+    const unsigned src = chunk_src(0, 0);
+#pragma unroll
+    for (int nb4 = 0; nb4 < 16; ++nb4) load_block(t[nb4], src, nb4, 0, 8);
+  }
+  // the accumulators start at zero (the map carries the layer's bias); written while the first loads are in flight
+#pragma unroll
+  for (int nb4 = 0; nb4 < 16; ++nb4) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc4[nb4][e] = 0.0f;
+    asm volatile("" : "+a"(acc4[nb4]));
+  }
+  int cx = 0, cy = 0;
+  auto chunk = [&](auto prefetch) {
+    constexpr bool PREFETCH = decltype(prefetch)::value;
+    // S: the corner weights of this lane's point for the lane's eight pixels of the chunk
+    float sv[8];
+    const int ry0 = y0 + 4 * cy + 2 * hl - ify, rx0 = x0 + 4 * cx - ifx;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int ry = ry0 + rr;
+      const float sf = ry == 0 ? cn.w[0] : (ry == 1 ? cn.w[2] : 0.0f);   // column fx: (fy,fx) / (cy,fx)
+      const float sc = ry == 0 ? cn.w[3] : (ry == 1 ? cn.w[1] : 0.0f);   // column cx: (fy,cx) / (cy,cx)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int rx = rx0 + cc;
+        sv[4 * rr + cc] = rx == 0 ? sf : (rx == 1 ? sc : 0.0f);
+      }
+    }
+    bf16x8 shi, slo;
+    split_bf16x8(sv, shi, slo);
+    if (++cx == ncx) { cx = 0; ++cy; }
+    const unsigned nsrc = chunk_src(cx, cy);
+    BlendSplit sp[2];
+    blend_split_ops<0, 20>(t[0], sp[0]);
+    static_for<16>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      BlendSplit& cu = sp[b & 1];
+      BlendSplit& nx = sp[(b + 1) & 1];
+      const bf16x8 ahi = __builtin_bit_cast(bf16x8, cu.hi), alo = __builtin_bit_cast(bf16x8, cu.lo);
+      SCHED_FENCE();
+      mfma1<true, true>(acc4[b], alo, shi);
+      SCHED_FENCE();
+      if constexpr (b < 15) blend_split_ops<0, 7>(t[b + 1], nx);
+      if constexpr (PREFETCH) load_block(t[b], nsrc, b, 0, 3);
+      SCHED_FENCE();
+      mfma1<true, true>(acc4[b], ahi, slo);
+      SCHED_FENCE();
+      if constexpr (b < 15) blend_split_ops<7, 14>(t[b + 1], nx);
+      if constexpr (PREFETCH) load_block(t[b], nsrc, b, 3, 6);
+      SCHED_FENCE();
+      mfma1<true, true>(acc4[b], ahi, shi);
+      SCHED_FENCE();
+      if constexpr (b < 15) blend_split_ops<14, 20>(t[b + 1], nx);
+      if constexpr (PREFETCH) load_block(t[b], nsrc, b, 6, 8);
+    });
+    SCHED_FENCE();
+  };
+#pragma unroll 1
+  for (int c = 1; c < nchunks; ++c) chunk(std::true_type{});
+  chunk(std::false_type{});
+}
+
 template <bool LOCAL, bool L4MX>
 __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const float* sp,
                                                 const float* b4 /*LDS: global stream's fold2/conv1 bias*/, uint4* park,
@@ -1399,6 +1534,24 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
     cn = corners(u, v);
   }
   if constexpr (LOCAL) {
+    // the wave's pixel rectangle (u, v lie in [0, 136]: project() clamps)
+    const int ifx = (int)floorf(u), ify = (int)floorf(v);
+    unsigned bx = (unsigned)ifx | ((255u - (unsigned)ifx) << 16), by = (unsigned)ify | ((255u - (unsigned)ify) << 16);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {   // (min, 255 - max) of both coordinates over the wave
+      const unsigned ox = (unsigned)__shfl_xor((int)bx, m, 64), oy = (unsigned)__shfl_xor((int)by, m, 64);
+      asm("v_pk_min_u16 %0, %0, %1" : "+v"(bx) : "v"(ox));
+      asm("v_pk_min_u16 %0, %0, %1" : "+v"(by) : "v"(oy));
+    }
+    bx = __builtin_amdgcn_readfirstlane(bx);
+    by = __builtin_amdgcn_readfirstlane(by);
+    const int x0 = (int)(bx & 0xffffu), x1 = 256 - (int)(bx >> 16), y0 = (int)(by & 0xffffu), y1 = 256 - (int)(by >> 16);
+    const int ncx = (x1 - x0 + 4) >> 2, nchunks = ncx * ((y1 - y0 + 4) >> 2);
+    if (nchunks <= BLEND_MAX_CHUNKS) {
+      unsigned vo = pipe.voff;   // lane * 16; re-derived here so that nothing lane-dependent is hoisted out of the tile loop
+      asm volatile("" : "+v"(vo));
+      blend_mfma(acc4, pmap, cn, ifx, ify, x0, y0, ncx, nchunks, (int)(vo >> 4));
+    } else {
     floatx4 t[2][16];
     auto gather = [&](floatx4 (&dst)[16], int nb4) {
 #pragma unroll
@@ -1427,6 +1580,7 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
             acc4[nb4][4 * q + e] = fmaf(cn.w[c], t[tb][4 * c + q][e], acc4[nb4][4 * q + e]);
       asm volatile("" : "+a"(acc4[nb4]));
     });
+    }
   } else {
 #pragma unroll
     for (int nb4 = 0; nb4 < 16; ++nb4) {
@@ -1434,6 +1588,15 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
       asm volatile("" : "+a"(acc4[nb4]));
     }
   }
+  if constexpr (LOCAL) {
+    // The fragment ring (32 registers: the first eight units of the tile's first stage, read at the end of the previous
+    // tile) is read again here instead of being carried through the image term, which wants the registers
+    static_for<8>([&](auto sc_) {
+      constexpr int S = decltype(sc_)::value;
+      ring_put<S>(rg, pipe.cur[S * 64]);
+    });
+  }
+  asm volatile("; disn:pipelined_region_begin" ::: "memory");
   int xl_scale = 127 - XL_SHIFT;
   asm volatile("" : "+v"(xl_scale));
   // fold1/conv1 (3 -> 64) on the VALU, laid out like two accumulator blocks and split in place
@@ -1992,7 +2155,10 @@ extern "C" int disn_sdf_set_image(DisnCtx* ctx, const float* const feat_maps[5],
   DISN_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t stream = (hipStream_t)stream_;
   DISN_TRY(disn_ensure(ctx, s->f137, (size_t)NPIX * FEAT_C * sizeof(float)));
-  DISN_TRY(disn_ensure(ctx, s->pmap, (size_t)NPIX * 512 * sizeof(float)));
+  if (s->pmap.cap < (size_t)PMAP_ROWS * 512 * sizeof(float)) {   // rows beyond the image: read with weight 0 by blend_mfma
+    DISN_TRY(disn_ensure(ctx, s->pmap, (size_t)PMAP_ROWS * 512 * sizeof(float)));
+    DISN_HIP(ctx, hipMemsetAsync((float*)s->pmap.p + (size_t)NPIX * 512, 0, (size_t)(PMAP_ROWS - NPIX) * 512 * sizeof(float), stream));
+  }
   for (int l = 0; l < 5; ++l) {
     long long n = (long long)NPIX * (LV_C[l] / 4);
     k_resize<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(feat_maps[l], LV_HW[l], LV_HW[l], LV_C[l],
@@ -2075,12 +2241,21 @@ static int selfcheck_run(DisnCtx* ctx, SdfState* s, const float* trans_mat, cons
   std::vector<float> pts(N * 3);
   const double g = 1.22074408460575947536;   // x^4 = x + 1
   const double al[3] = {1.0 / g, 1.0 / (g * g), 1.0 / (g * g * g)};
-  for (size_t i = 0; i < N; ++i)
+  // First half: patches of 8 x 4 points 1/256 of the box apart around low-discrepancy anchors -- 32 consecutive points
+  // are one wave of the decoder, whose pixel rectangle is then as small as in a dense grid, so the image term takes the
+  // matrix-product path (blend_mfma); second half: scattered points (the gather path).
+  const size_t npatch = N / 64;
+  for (size_t i = 0; i < N; ++i) {
+    const bool patch = i < 32 * npatch;
+    const size_t a = patch ? i / 32 : i;
+    const int off[3] = {(int)(i & 7), (int)((i >> 3) & 3), 0};
     for (int c = 0; c < 3; ++c) {
-      double u = 0.5 + al[c] * (double)(i + 1);
+      double u = 0.5 + al[c] * (double)(a + 1);
       u -= floor(u);
+      if (patch) u = u * (248.0 / 256.0) + off[c] / 256.0;
       pts[3 * i + c] = (float)(sdf_params[c] + u * (sdf_params[3 + c] - sdf_params[c]));
     }
+  }
   DISN_HIP(ctx, hipMemcpyAsync(B + o_pts, pts.data(), N * 3 * sizeof(float), hipMemcpyHostToDevice, stream));
   DISN_HIP(ctx, hipMemcpyAsync(B + o_tm, trans_mat, 12 * sizeof(float), hipMemcpyHostToDevice, stream));
   DISN_HIP(ctx, hipStreamSynchronize(stream));   // pts is a local
@@ -2193,7 +2368,7 @@ extern "C" int disn_sdf_grid(DisnCtx* ctx, const float* trans_mat, const double*
     a.step[q] = (sdf_params[3 + q] - sdf_params[q]) / (double)res;  // np.linspace: delta / div
   }
   a.n = (long long)(z1 - z0 + 1) * (res + 1) * (res + 1);
-  // tiles: bricks of 8 x 4 x 4 points over the core of the slab, the rest linearly (grid_point)
+  // tiles: bricks of 8 x 4 x 4 points over the core of the slab, the rest wave by wave (grid_point)
   a.n1 = res + 1;
   a.nk = z1 - z0 + 1;
   a.ic = a.n1 & ~7; a.jc = a.n1 & ~3; a.kc = a.nk & ~3;
@@ -2202,11 +2377,13 @@ extern "C" int disn_sdf_grid(DisnCtx* ctx, const float* trans_mat, const double*
   a.sbi = pow2_div(nbi, 2); a.sbj = pow2_div(nbj, 3); a.sbk = pow2_div(nbk, 3);   // super-brick <= 32^3 points
   a.nsi = nbi >> a.sbi; a.nsj = nbj >> a.sbj;
   a.core_tiles = (long long)nbi * nbj * nbk;
-  const long long r1 = (long long)(a.nk - a.kc) * a.n1 * a.n1, r2 = (long long)a.kc * (a.n1 - a.jc) * a.n1;
-  const long long r3 = (long long)a.kc * a.jc * (a.n1 - a.ic);
+  // waves of the remainder regions (grid_point): patches of the planes k >= kc, runs of 32 along the rows j >= jc, runs
+  // of 32 along the columns i >= ic (j < jc)
+  const long long r1 = (long long)(a.nk - a.kc) * nbi * nbj, r2 = (long long)a.nk * (a.n1 - a.jc) * ((a.n1 + 31) / 32);
+  const long long r3 = (long long)a.nk * (a.n1 - a.ic) * ((a.jc + 31) / 32);
   if (a.core_tiles == 0) { a.nsi = a.nsj = 1; }
   a.r1 = (unsigned)r1; a.r2 = (unsigned)r2; a.r3 = (unsigned)r3;
-  a.ntiles = a.core_tiles + (r1 + r2 + r3 + 127) / 128;
+  a.ntiles = a.core_tiles + (r1 + r2 + r3 + 3) / 4;
   a.scale_out = 1;
   a.out = sdf_out;
   return launch_decode(ctx, a, trans_mat, (hipStream_t)stream);

@@ -66,8 +66,12 @@ def test_config1_res256_full(ctx):
     sdf = pipe.last_sdf
     assert tuple(sdf.shape) == (257, 257, 257)
     # every second point of every second plane is the sdf_res-128 grid (linspace end and mid points are exact)
+    # -- to the rounding of the image term, which the mixed decoders compute over each wave's pixel rectangle (another
+    # rectangle at another resolution; tests/test_gpu_sdf.py GRID_VS_POINTS)
     coarse = ctx.sdf_grid(synth.GT_TRANS_MAT, 128)
-    assert torch.equal(sdf[::2, ::2, ::2], coarse)
+    sub = float((sdf[::2, ::2, ::2] - coarse).abs().max())
+    print("res 256 vs res 128 on the shared points: max |diff| %.2e" % sub)
+    assert sub <= 2e-6
     del coarse
     # 250 000 sampled points against the float64 oracle
     got = sdf.cpu().numpy()
@@ -100,7 +104,7 @@ def _slabs_equal_single_pass(ctx, res, nslabs, seed):
     sdf = ctx.sdf_grid(synth.GT_TRANS_MAT, res)
     # a plane of this grid is a plane of the grid at half the resolution (linspace end and mid points are exact)
     coarse = ctx.sdf_grid(synth.GT_TRANS_MAT, res // 2, z0=res // 8, z1=res // 8)
-    assert torch.equal(sdf[res // 4, ::2, ::2], coarse[0])
+    assert float((sdf[res // 4, ::2, ::2] - coarse[0]).abs().max()) <= 2e-6   # (to the image term's rounding)
     ctx.mc_count(sdf, iso)
     v1, t1 = ctx.mc_emit()
     del sdf

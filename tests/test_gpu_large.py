@@ -51,7 +51,8 @@ def test_res512_pipeline_invariants(ctx):
     assert sdf.shape == (513, 513, 513) and bool(torch.isfinite(sdf).all())
     # every other plane of the 512 grid is a plane of the 256 grid (same points: linspace endpoints and midpoints are exact)
     coarse = ctx.sdf_grid(synth.GT_TRANS_MAT, 256, z0=64, z1=64)
-    assert torch.equal(sdf[128, ::2, ::2], coarse[0])
+    # (to the rounding of the image term over each wave's pixel rectangle: tests/test_gpu_sdf.py GRID_VS_POINTS)
+    assert float((sdf[128, ::2, ::2] - coarse[0]).abs().max()) <= 2e-6
     iso = median_iso(sdf)
     ctx.mc_count(sdf, iso)
     v, f, k = ctx.mc_emit(want_keys=True)

@@ -104,19 +104,33 @@ def test_large_scale_weights_stay_in_tolerance(ctx):
     assert np.abs(got - want64).max() / 10.0 <= TOL_SDF
 
 
-def test_linearity_of_image_term_at_full_res_plane(ctx, model):
+# The mixed decoders compute the image term of fold2/conv1 per wave, as a matrix product over the wave's pixel rectangle
+# (bf16 triple, ~2^-17 relative), when the wave's 32 points project close together -- a dense grid -- and as the exact-fp32
+# corner blend otherwise (scattered points).  Grid launches and point launches of the same points therefore agree to that
+# rounding, not to the bit; the bf16x3 decoder always blends in fp32 and agrees bit for bit.
+GRID_VS_POINTS = {"mixed4": 3e-6, "mixed": 2e-6, "bf16x3": 0.0}   # after the /10; measured 1.4e-6 / 6e-7 at most
+
+
+@pytest.mark.parametrize("decoder", ["mixed4", "bf16x3"])
+def test_linearity_of_image_term_at_full_res_plane(ctx, model, decoder):
     """Size-independent property at the bench size: one z-plane of the res-256 grid
     equals sdf_points on the same points (grid generation == np.linspace)."""
     maps, gf, w = model
-    ctx.set_weights(w)
-    ctx.set_image(maps, gf)
-    plane = ctx.sdf_grid(net.GT_TRANS_MAT, 256, z0=100, z1=100)
-    l = np.linspace(-1, 1, 257)
-    y, x = np.meshgrid(l, l, indexing="ij")
-    pts = np.stack([x, y, np.full_like(x, l[100])], -1).astype(np.float32).reshape(-1, 3)
-    raw = ctx.sdf_points(net.GT_TRANS_MAT, pts)
-    want = (raw.double() / 10.0).float().reshape(257, 257)
-    assert torch.equal(plane[0], want)
+    ctx.set_decoder(decoder)
+    try:
+        ctx.set_weights(w)
+        ctx.set_image(maps, gf)
+        plane = ctx.sdf_grid(net.GT_TRANS_MAT, 256, z0=100, z1=100)
+        l = np.linspace(-1, 1, 257)
+        y, x = np.meshgrid(l, l, indexing="ij")
+        pts = np.stack([x, y, np.full_like(x, l[100])], -1).astype(np.float32).reshape(-1, 3)
+        raw = ctx.sdf_points(net.GT_TRANS_MAT, pts)
+        want = (raw.double() / 10.0).float().reshape(257, 257)
+        diff = float((plane[0] - want).abs().max())
+        print("%s: res-256 plane, grid vs points max |diff| %.2e" % (decoder, diff))
+        assert diff <= GRID_VS_POINTS[decoder]
+    finally:
+        ctx.set_decoder("auto")
 
 
 def test_state_errors(ctx):
@@ -133,21 +147,45 @@ def test_state_errors(ctx):
 @pytest.mark.parametrize("res,z0,z1", [(1, 0, 1), (2, 1, 2), (3, 0, 3), (7, 0, 7), (8, 0, 8), (12, 1, 11), (20, 0, 3), (33, 5, 5),
                                         (40, 0, 40), (64, 0, 64), (64, 7, 38)])
 def test_grid_tiling_matches_points_mode(ctx, model, decoder, res, z0, z1):
-    """The grid is walked in bricks of 8 x 4 x 4 points (super-bricks for L2 locality) plus three linear remainder
-    boxes: every (res, slab) shape -- core only, remainders only, both -- must give, bit for bit, what the same
-    points give through disn_sdf_points (one point's result does not depend on its tile)."""
+    """The grid is walked in bricks of 8 x 4 x 4 points (super-bricks for L2 locality) plus the remainder regions wave by
+    wave: every (res, slab) shape -- core only, remainders only, both -- must give what the same points give through
+    disn_sdf_points: every point written, none misplaced; bit for bit with the bf16x3 decoder (GRID_VS_POINTS)."""
     maps, gf, w = model
     ctx.set_decoder(decoder)
     try:
         ctx.set_weights(w)
         ctx.set_image(maps, gf)
-        got = ctx.sdf_grid(net.GT_TRANS_MAT, res, z0=z0, z1=z1)
+        got = torch.full((z1 - z0 + 1, res + 1, res + 1), float("nan"), device=ctx.device)
+        ctx.sdf_grid(net.GT_TRANS_MAT, res, z0=z0, z1=z1, out=got)
         l = np.linspace(-1, 1, res + 1)
         z, y, x = np.meshgrid(l[z0:z1 + 1], l, l, indexing="ij")
         pts = np.stack([x, y, z], -1).astype(np.float32).reshape(-1, 3)
         raw = ctx.sdf_points(net.GT_TRANS_MAT, pts)
         want = (raw.double() / 10.0).float().reshape(z1 - z0 + 1, res + 1, res + 1)
-        assert torch.equal(got, want)
+        assert not bool(torch.isnan(got).any())
+        assert float((got - want).abs().max()) <= GRID_VS_POINTS[decoder]
+    finally:
+        ctx.set_decoder("auto")
+
+
+@pytest.mark.parametrize("decoder", ["mixed4", "mixed", "bf16x3"])
+@pytest.mark.parametrize("res,cuts", [(12, (0, 1, 2, 7, 13)), (33, (0, 5, 6, 19, 34)), (64, (0, 7, 39, 40, 42, 65)),
+                                      (37, (0, 3, 38)), (96, (0, 13, 50, 97))])
+def test_grid_values_do_not_depend_on_the_slab_cut(ctx, model, decoder, res, cuts):
+    """What multi-GPU runs rest on: a grid point's value is the same bits whichever z-slab it is evaluated in (halo planes
+    evaluated by two ranks, N ranks against one).  Holds because a point shares its wave -- hence the pixel rectangle the
+    image term is computed over -- with the same 31 points under every cut (grid_point's enumeration)."""
+    maps, gf, w = model
+    ctx.set_decoder(decoder)
+    try:
+        ctx.set_weights(w)
+        ctx.set_image(maps, gf)
+        whole = ctx.sdf_grid(net.GT_TRANS_MAT, res)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            part = ctx.sdf_grid(net.GT_TRANS_MAT, res, z0=a, z1=b - 1)
+            assert torch.equal(part, whole[a:b]), (a, b)
+        lo = ctx.sdf_grid(net.GT_TRANS_MAT, res, z0=1, z1=min(res, 6))      # overlapping slabs (halo = "recompute")
+        assert torch.equal(lo, whole[1:min(res, 6) + 1])
     finally:
         ctx.set_decoder("auto")
 

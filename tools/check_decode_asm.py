@@ -6,7 +6,8 @@ LDS-DMA pieces they issue.  Both assumptions hold only while, between the first 
   * hipcc never touches M0 (only our `s_mov_b32 m0, sN`),
   * hipcc emits no vector-memory instruction of its own: no scratch spill/reload, no global/buffer load or store
     (each would shift the hand-counted vmcnt, and its own wait would be computed without our LDS-DMA pieces).
-Outside that region (point set-up and Pmap gather before the first MFMA, the result store after the last) the
+Outside that region (point set-up and the image term before the first MFMA of the layers -- marked by the kernel with
+a `disn:pipelined_region_begin` comment when that set-up uses MFMAs itself -- and the result store after the last) the
 compiler's own memory instructions are fine.  Fails the build otherwise."""
 import re
 import sys
@@ -34,10 +35,17 @@ def check_one(name, lines):
     if not mf:
         sys.exit("check_decode_asm: no MFMA in %s" % name)
     first, last = mf[0], mf[-1]
+    # kernels whose point set-up itself uses MFMAs (the image term as a matrix product) mark where the pipelined region
+    # begins; a kernel that walks both streams has one marker per stream and the region starts at the first
+    marks = [i for i, l in enumerate(lines) if "disn:pipelined_region_begin" in l]
+    if marks:
+        first = min(marks)
     bad = []
     for i, l in enumerate(code):
         if re.search(r"\bm0\b", l) and not re.fullmatch(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi|ttmp\d+)", l):
             bad.append((i, "M0 used by the compiler: " + l))
+        if l.startswith("scratch_"):
+            bad.append((i, "register spill (the decoders are meant to fit the register file): " + l))
         if first < i < last:
             if l.startswith(("scratch_", "buffer_", "global_store", "flat_")) or \
                (l.startswith("global_load") and not l.startswith("global_load_lds_dword")):
