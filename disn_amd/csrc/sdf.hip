@@ -1417,6 +1417,19 @@ __device__ __forceinline__ void split_bf16x8(const float (&v)[8], bf16x8& hi, bf
   hi = __builtin_bit_cast(bf16x8, h);
   lo = __builtin_bit_cast(bf16x8, l);
 }
+// min / max over lanes 0..31 of a wave whose lanes 32..63 repeat them, by DPP (five steps; ds_bpermute shuffles cost a
+// dependent LDS round trip each): quads, half rows, rows, then row 0 into row 1; the result is read off lane 31.
+template <bool MAX>
+__device__ __forceinline__ int wave32_reduce(int v) {
+#define DISN_RED_STEP(ctrl, rows) { const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, rows, 0xf, false); v = MAX ? max(v, o) : min(v, o); }
+  DISN_RED_STEP(0xB1, 0xf)    // quad_perm [1,0,3,2]
+  DISN_RED_STEP(0x4E, 0xf)    // quad_perm [2,3,0,1]
+  DISN_RED_STEP(0x141, 0xf)   // row_half_mirror
+  DISN_RED_STEP(0x140, 0xf)   // row_mirror
+  DISN_RED_STEP(0x142, 0xa)   // row_bcast15 into rows 1, 3
+#undef DISN_RED_STEP
+  return __builtin_amdgcn_readlane(v, 31);
+}
 // The split of one block's eight values (four pairs) as 20 single VALU ops in stage-major order -- hi pairs (RNE), their
 // two expansions, the exact packed subtraction, lo pairs -- so that neighbours in the instruction stream are independent
 // and a third of them fits the shadow of each of the previous block's three MFMAs.
@@ -1536,16 +1549,8 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
   if constexpr (LOCAL) {
     // the wave's pixel rectangle (u, v lie in [0, 136]: project() clamps)
     const int ifx = (int)floorf(u), ify = (int)floorf(v);
-    unsigned bx = (unsigned)ifx | ((255u - (unsigned)ifx) << 16), by = (unsigned)ify | ((255u - (unsigned)ify) << 16);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {   // (min, 255 - max) of both coordinates over the wave
-      const unsigned ox = (unsigned)__shfl_xor((int)bx, m, 64), oy = (unsigned)__shfl_xor((int)by, m, 64);
-      asm("v_pk_min_u16 %0, %0, %1" : "+v"(bx) : "v"(ox));
-      asm("v_pk_min_u16 %0, %0, %1" : "+v"(by) : "v"(oy));
-    }
-    bx = __builtin_amdgcn_readfirstlane(bx);
-    by = __builtin_amdgcn_readfirstlane(by);
-    const int x0 = (int)(bx & 0xffffu), x1 = 256 - (int)(bx >> 16), y0 = (int)(by & 0xffffu), y1 = 256 - (int)(by >> 16);
+    const int x0 = wave32_reduce<false>(ifx), x1 = wave32_reduce<true>(ifx) + 1;
+    const int y0 = wave32_reduce<false>(ify), y1 = wave32_reduce<true>(ify) + 1;
     const int ncx = (x1 - x0 + 4) >> 2, nchunks = ncx * ((y1 - y0 + 4) >> 2);
     if (nchunks <= BLEND_MAX_CHUNKS) {
       unsigned vo = pipe.voff;   // lane * 16; re-derived here so that nothing lane-dependent is hoisted out of the tile loop
@@ -1599,28 +1604,50 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
   asm volatile("; disn:pipelined_region_begin" ::: "memory");
   int xl_scale = 127 - XL_SHIFT;
   asm volatile("" : "+v"(xl_scale));
-  // fold1/conv1 (3 -> 64) on the VALU, laid out like two accumulator blocks and split in place
+  // fold1/conv1 (3 -> 64) on the VALU, laid out like two accumulator blocks and split in place.  All LDS reads of a phase
+  // are issued as one batch from one base address, fenced ahead of their uses: left to itself, hipcc at the register
+  // limit issues each read just before its use and waits out the LDS latency 32 times (4 K cycles per tile and stream
+  // in fold1/conv2's bias reads alone, tools/seg_patch_mx4.py)
   XG x1;
+  XG h2[4];
+  {
+    const float* w1 = sp + SP_W1 + 16 * half_of();
+    const float* b2 = sp + SP_B2 + 4 * half_of();
+    floatx4 wa[16], wb[16];
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int f = (g & 3) + 8 * (g >> 2) + 4 * half_of();
-    floatx4 wa = *(const floatx4*)(sp + SP_W1 + 4 * f);
-    floatx4 wb = *(const floatx4*)(sp + SP_W1 + 4 * (32 + f));
-    x1.a[g] = __float_as_int(fmaf(pz, wa[2], fmaf(py, wa[1], px * wa[0])) + wa[3]);
-    x1.b[g] = __float_as_int(fmaf(pz, wb[2], fmaf(py, wb[1], px * wb[0])) + wb[3]);
+    for (int g = 0; g < 16; ++g) {
+      const int f = (g & 3) + 8 * (g >> 2);
+      wa[g] = *(const floatx4*)(w1 + 4 * f);
+      wb[g] = *(const floatx4*)(w1 + 4 * (32 + f));
+    }
+    SCHED_FENCE();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      x1.a[g] = __float_as_int(fmaf(pz, wa[g][2], fmaf(py, wa[g][1], px * wa[g][0])) + wa[g][3]);
+      x1.b[g] = __float_as_int(fmaf(pz, wb[g][2], fmaf(py, wb[g][1], px * wb[g][0])) + wb[g][3]);
+    }
+    SCHED_FENCE();
+    // fold1/conv2's bias into its eight accumulator blocks (h2[2 st + p].a / .b = block 4 st + 2 p / + 1); the reads land
+    // while x1 is split
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) {
+      intx16& dst = (blk & 1) ? h2[blk >> 1].b : h2[blk >> 1].a;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const floatx4 v = *(const floatx4*)(b2 + 32 * blk + 8 * q);
+        dst[4 * q + 0] = __float_as_int(v[0]); dst[4 * q + 1] = __float_as_int(v[1]);
+        dst[4 * q + 2] = __float_as_int(v[2]); dst[4 * q + 3] = __float_as_int(v[3]);
+      }
+    }
+    SCHED_FENCE();
   }
   cvt_mx_all(x1);
   // fold1/conv2 (64 -> 256): 2 stages of 4 blocks (one group each); h2 stays resident as 4 operand groups
-  XG h2[4];
   {
     const Scales sc = {load_scale(sp, 0), xl_scale};
     asm volatile("s_nop 7" ::: "memory");   // the split of h1 was written by VALU conversions just above
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      h2[2 * st].a = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 0), half_of()));
-      h2[2 * st].b = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 1), half_of()));
-      h2[2 * st + 1].a = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 2), half_of()));
-      h2[2 * st + 1].b = as_bits(bias_init(sp + SP_B2, 32 * (4 * st + 3), half_of()));
       group_step<0, false>(pipe, rg, h2[2 * st].a, x1, sc, [](auto) {});
       group_step<1, false>(pipe, rg, h2[2 * st].b, x1, sc, [](auto) {});
       group_step<2, false>(pipe, rg, h2[2 * st + 1].a, x1, sc, [](auto) {});
@@ -1745,16 +1772,26 @@ __device__ __forceinline__ float stream_pass_mx(Pipe& pipe, Ring8& rg, const flo
     });
   });
   }
-  float part = 0.0f;
+  // fold2/conv3 (256 -> 1) on the VALU: the lane's 128 weights in two batches of 16 reads (see fold1/conv1), four
+  // independent partial sums
+  drain_v(acc5[7]);
+  float part;
+  {
+    const float* w6 = sp + SP_W6 + 4 * half_of();
+    float ps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    static_for<2>([&](auto hc) {
+      constexpr int H = decltype(hc)::value;
+      floatx4 w[16];
 #pragma unroll
-  for (int nb = 0; nb < 8; ++nb) {
-    drain_v(acc5[nb]);
+      for (int r = 0; r < 16; ++r) w[r] = *(const floatx4*)(w6 + 32 * (4 * H + (r >> 2)) + 8 * (r & 3));
+      SCHED_FENCE();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      floatx4 w = *(const floatx4*)(sp + SP_W6 + 32 * nb + 8 * q + 4 * half_of());
+      for (int r = 0; r < 16; ++r)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) part = fmaf(fmaxf(acc5[nb][4 * q + e], 0.0f), w[e], part);
-    }
+        for (int e = 0; e < 4; ++e) ps[e] = fmaf(relu1(acc5[4 * H + (r >> 2)][4 * (r & 3) + e]), w[r][e], ps[e]);
+      SCHED_FENCE();
+    });
+    part = (ps[0] + ps[1]) + (ps[2] + ps[3]);
   }
   part += __shfl_xor(part, 32, 64);
   return part + sp[SP_B6];
