@@ -119,7 +119,13 @@ int disn_sdf_set_image(DisnCtx* ctx, const float* const feat_maps[5], const floa
  *   sdf_params: HOST double[6] = lo xyz, hi xyz (demo/demo.py:278)
  *   res       : sdf_res (grid has res+1 points per axis)
  *   z0,z1     : inclusive plane range to evaluate (z-slab); whole grid = 0,res
- *   sdf_out   : DEVICE float[(z1-z0+1)*(res+1)^2], x fastest then y then z */
+ *   sdf_out   : DEVICE float[(z1-z0+1)*(res+1)^2], x fastest then y then z
+ * A grid point's value is the same bits for every z0,z1 it is evaluated under (z-slabs on several GPUs reproduce the
+ * single launch).  With the mixed decoders it may differ in the last bits (<= 2e-6 after the /10) from what
+ * disn_sdf_points returns for the same point, and from the same point of a grid of another res: the image term of the
+ * local stream is evaluated over the pixel rectangle of the 32 points that share a wave (bf16 triple on the matrix
+ * cores) when they project close together, and as the fp32 four-corner blend otherwise.  DISN_DECODER_BF16X3 always
+ * blends in fp32 and is bit-identical between the two entry points. */
 int disn_sdf_grid(DisnCtx* ctx, const float* trans_mat, const double* sdf_params, int res,
                   int z0, int z1, float* sdf_out, void* stream);
 
