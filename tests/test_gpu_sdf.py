@@ -190,6 +190,40 @@ def test_grid_values_do_not_depend_on_the_slab_cut(ctx, model, decoder, res, cut
         ctx.set_decoder("auto")
 
 
+@pytest.mark.parametrize("du,dv", [(66.0, 66.0), (-71.0, -71.0), (66.0, -71.0), (-71.0, 66.0), (0.0, 0.0)])
+def test_image_term_at_the_image_border(ctx, model, du, dv):
+    """Dense grid over a small box whose projections run off the 137 x 137 image (the camera matrix with its principal
+    point moved by (du, dv) pixels; coordinates clamp to 0 / 136): the wave rectangles of the matrix-product image term
+    then end at the last pixel row / column and their chunks reach into the zeroed tail of the pixel map with weight 0.
+    Three planes of a sdf_res-96 grid against the float64 oracle, all decoders."""
+    maps, gf, w = model
+    tm = np.asarray(net.GT_TRANS_MAT, dtype=np.float64).reshape(4, 3).copy()
+    tm[:, 0] += du * tm[:, 2]
+    tm[:, 1] += dv * tm[:, 2]
+    tm = tm.astype(np.float32)
+    box = (-0.15, -0.15, -0.15, 0.15, 0.15, 0.15)
+    res, z0, z1 = 96, 47, 49
+    ax = [np.linspace(box[a], box[3 + a], res + 1) for a in range(3)]
+    z, y, x = np.meshgrid(ax[2][z0:z1 + 1], ax[1], ax[0], indexing="ij")
+    pts = np.stack([x, y, z], -1).astype(np.float32).reshape(-1, 3)
+    uv = net.get_img_points(pts, tm)
+    clamped = float(np.mean((uv == 0.0) | (uv == 136.0)))
+    assert (du == 0.0) == (clamped == 0.0)      # the shifted cameras do push points over the border
+    want = (net.sdf_points(pts, pts, tm, maps, gf, w, dtype=torch.float64) / 10.0).reshape(z1 - z0 + 1, res + 1, res + 1)
+    try:
+        for dec in ("mixed4", "mixed", "bf16x3"):
+            ctx.set_decoder(dec)
+            ctx.set_weights(w)
+            ctx.set_image(maps, gf)
+            got = ctx.sdf_grid(tm, res, z0=z0, z1=z1, sdf_params=box).cpu().numpy()
+            err = float(np.abs(got - want).max())
+            print("%s shift (%g, %g): u in [%.1f, %.1f], v in [%.1f, %.1f], %.0f %% of coordinates clamped, max err %.2e" %
+                  (dec, du, dv, uv[:, 0].min(), uv[:, 0].max(), uv[:, 1].min(), uv[:, 1].max(), 100 * clamped, err))
+            assert np.isfinite(got).all() and err <= TOL_SDF
+    finally:
+        ctx.set_decoder("auto")
+
+
 def test_decoders_agree_and_meet_tolerance(ctx, model):
     """All three decoder arithmetics (disn_sdf_set_decoder) against the float64 oracle on the same points."""
     maps, gf, w = model
