@@ -1399,7 +1399,9 @@ __device__ __forceinline__ void l3_stage_mx(Pipe& pipe, Ring8& rg, intx16& acc3,
 // splits the eight values into bf16 hi + lo, and three products (lo.hi, hi.lo, hi.hi; fp32 accumulate, ~2^-17 relative,
 // as in the bf16 triple) land in the accumulator block.  Pixel rows beyond the image carry weight 0 and are read from
 // the zeroed tail of the Pmap buffer (PMAP_ROWS).  Waves whose rectangle needs more than BLEND_MAX_CHUNKS chunks
-// (scattered points, very coarse grids) take the gather instead.
+// (scattered points, very coarse grids) take the gather instead.  Every pixel of the rectangle enters every point's sum,
+// most with weight 0: a non-finite map entry (features that overflowed fp32) spoils the wave's 32 points, not only the
+// points that sample it.
 #ifndef BLEND_MAX_CHUNKS
 #define BLEND_MAX_CHUNKS 12
 #endif

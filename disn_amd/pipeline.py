@@ -253,9 +253,10 @@ def median_iso(sdf):
     return float(torch.median(sdf.reshape(-1)).item())
 
 
-def coarse_median_iso(ctx, trans_mat, sdf_params=(-1, -1, -1, 1, 1, 1), res=32):
-    """Median of the SDF over a coarse (res+1)^3 grid spanning the WHOLE box (36 K points, one small
-    launch): the iso used with random-init weights, which have no zero level set.  It needs the image
+def coarse_median_iso(ctx, trans_mat, sdf_params=(-1, -1, -1, 1, 1, 1), res=31):
+    """Median of the SDF over a coarse (res+1)^3 grid spanning the WHOLE box (32^3 points = 256 tiles of 128: one
+    tile per compute unit, one round of the decoder's persistent workgroups): the iso used with random-init
+    weights, which have no zero level set.  It needs the image
     to be set (ctx.set_image) and is the same number on every rank, whatever slab the rank owns."""
     return median_iso(ctx.sdf_grid(trans_mat, res, sdf_params=sdf_params))
 

@@ -75,7 +75,8 @@ int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w);
  *                       block-scaled MFMA) residual products; fold2/conv2: three bf16 products.
  *                       Activations of the first three layers beyond 448 lose their residual terms
  *                       (conversions saturate); weights must lie inside the fp16 range.
- *   DISN_DECODER_BF16X3 three bf16 products (hi/lo split of both operands) in every layer: 1.33x the matrix time.
+ *   DISN_DECODER_BF16X3 three bf16 products (hi/lo split of both operands) in every layer: 1.33x the matrix time;
+ *                       the image term of the local stream as the fp32 four-corner blend for every point.
  * Takes effect at the next disn_sdf_grid / disn_sdf_points. */
 #define DISN_DECODER_MIXED 0
 #define DISN_DECODER_BF16X3 1
@@ -84,7 +85,9 @@ int disn_sdf_set_weights(DisnCtx* ctx, const DisnDecoderWeights* w);
 int disn_sdf_set_decoder(DisnCtx* ctx, int decoder);
 
 /* Accuracy self-check (no counterpart in the reference, whose graph is plain fp32 and needs none): n_points
- * sample points spread over the sdf_params box are evaluated through the AS-WRITTEN fp32 graph on the device
+ * sample points spread over the sdf_params box (half of them in patches of 8 x 4 points 1/256 of the box apart, the
+ * arrangement of a dense grid's waves, half scattered: the mixed decoders evaluate the image term differently for the
+ * two, see disn_sdf_grid) are evaluated through the AS-WRITTEN fp32 graph on the device
  * (reference models/model_normalization.py:169-206,241-251, models/sdfnet.py:69-92,171-190: projection, five
  * resized maps sampled and concatenated, tiled global feature, every 1x1 convolution as an exact fp32 GEMM, no
  * algebraic shortcut) and through the selected decoder; *max_abs_err = max |difference| of the two SDFs (after
