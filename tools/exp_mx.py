@@ -1,3 +1,5 @@
+# NOTE: timing-only variants of the ROUND-2 kernels (patch anchors no longer match the source); kept as the record of how
+# the round-2 numbers in DESIGN.md s3.1 were taken.  Current kernels: tools/seg_patch_mx4.py.
 """timing-only variants of sdf_decode_mx (experiment, not product): builds tools/dbg/libdisn_<name>.so with the
 per-segment counters of tools/seg_patch_mx.py plus one thing removed, so that the per-stage cost of that thing can be
 read off tools/seg_probe_mx.py (results of these variants are WRONG on purpose).  Run here: python tools/exp_mx.py

@@ -1,3 +1,5 @@
+# NOTE: written against the round-2 kernels (its anchors no longer match the source); the current kernels are profiled
+# with tools/seg_patch_mx4.py / tools/seg_probe_mx4.py.
 # per-segment cycle counters for sdf_decode_mx (applied to a copy of sdf.hip by tools/seg.sh with SEGPATCH=tools/seg_patch_mx.py)
 def rep(a, b):
     global s

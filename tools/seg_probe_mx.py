@@ -1,3 +1,4 @@
+"""NOTE: goes with tools/seg_patch_mx.py (round-2 kernels); current kernels: tools/seg_probe_mx4.py."""
 """per-segment shader cycles of sdf_decode_mx (needs tools/seg_patch_mx.py applied; experiment only)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
