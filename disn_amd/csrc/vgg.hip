@@ -13,6 +13,8 @@
 
 #include <vector>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -47,19 +49,22 @@ __global__ void k_resize_pad4(const float* __restrict__ in, int ih, int iw, int 
 // 3x3 SAME convolution, stride 1, NHWC, as an implicit GEMM:  C[m][n] = sum_k A[m][k] B[k][n],
 // m = y*W + x, k = tap*cin + ci (tap = 3*(dy+1) + (dx+1)), A[m][k] = in[y+dy][x+dx][ci] (0 outside the image),
 // B = the HWIO weights [9*cin (zero rows up to kpad)][n].  cin is a power of two >= 4 (1 << cin_shift).
-// 128 x 128 tile per workgroup, 4 waves of 64 x 64 (2 x 2 MFMA tiles of 32 x 32), 16 k per LDS stage.
+// 128 x TN tile per workgroup (TN = 128; 64 for the two 64-channel layers, which would waste half of a 128-wide tile),
+// 4 waves of 64 x TN/2 (2 x TN/64 MFMA tiles of 32 x 32), 16 k per LDS stage.
 // blockIdx.z = K split: split s takes stages [s*per, (s+1)*per) and writes its partial sums to
 // part[s][M][N] (nsplit > 1) or the finished relu(acc + bias) to out (nsplit == 1).
+template <int TN>
 __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, const float* __restrict__ Wt,
                                                  const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                  int cin_shift, int N, int kpad, int per, int nsplit) {
   __shared__ float As[GK][GT + 4];
-  __shared__ float Bs[GK][GT + 4];
+  __shared__ float Bs[GK][TN + 4];
+  constexpr int NB = TN / 64;   // MFMA tiles of a wave along N
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int M = H * W;
-  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
-  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * TN;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * (TN / 2);
   const int cin = 1 << cin_shift;
   // the two A rows this thread loads in every stage
   int py[2], px[2];
@@ -72,11 +77,11 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
     px[q] = m - py[q] * W;
   }
   const int kq = (threadIdx.x & 3) * 4;
-  floatx16 acc[2][2];
+  floatx16 acc[2][NB];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.0f;
   const int s0 = blockIdx.z * per, s1 = min(kpad / GK, s0 + per);
@@ -96,9 +101,9 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
       }
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < TN / 64; ++q) {
       int idx = threadIdx.x + q * 256;
-      int kr = idx >> 5, cq = (idx & 31) * 4;
+      int kr = idx / (TN / 4), cq = (idx % (TN / 4)) * 4;
       floatx4 v = {0, 0, 0, 0};
       if (n0 + cq < N) v = *(const floatx4*)(Wt + (size_t)(k0 + kr) * N + n0 + cq);
       *(floatx4*)&Bs[kr][cq] = v;
@@ -106,12 +111,13 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 2) {
-      float a0 = As[kk + h][wm + r], a1 = As[kk + h][wm + 32 + r];
-      float b0 = Bs[kk + h][wn + r], b1 = Bs[kk + h][wn + 32 + r];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      const float a0 = As[kk + h][wm + r], a1 = As[kk + h][wm + 32 + r];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float bv = Bs[kk + h][wn + 32 * b + r];
+        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][b], 0, 0, 0);
+        acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][b], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         int row = m0 + wm + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
@@ -186,8 +192,42 @@ __global__ __launch_bounds__(256) void k_fc_partial(const float* __restrict__ x,
   *(floatx4*)(part + (size_t)blockIdx.y * N + n) = s;
 }
 
+// The same sum for the few outputs of a fully connected layer (1024 .. 4096) over many partials (128 .. 512): a
+// workgroup takes 128 outputs; its 8 groups of 32 threads each add one eighth of the partials in order, and the eight
+// group sums are added in group order -- a fixed association, 8 x fewer dependent loads per thread than one serial loop
+// (which took 50 us for fc6's 196 partials on four workgroups).
+__global__ __launch_bounds__(256) void k_sum_splits_fc(const float* __restrict__ part, int nsplit, int N, const float* __restrict__ bias,
+                                                       int relu, float* __restrict__ out) {
+  __shared__ floatx4 lds[8][32];
+  const int q = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int n = (blockIdx.x * 32 + q) * 4;
+  const int per = (nsplit + 7) / 8, p0 = g * per, p1 = min(nsplit, p0 + per);
+  floatx4 s = {0, 0, 0, 0};
+  if (n < N)
+    for (int p = p0; p < p1; ++p) {
+      const floatx4 v = *(const floatx4*)(part + (size_t)p * N + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = __fadd_rn(s[e], v[e]);
+    }
+  lds[g][q] = s;
+  __syncthreads();
+  if (g == 0 && n < N) {
+    floatx4 t = lds[0][q];
+    for (int gg = 1; gg < 8; ++gg)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = __fadd_rn(t[e], lds[gg][q][e]);
+    const floatx4 b = *(const floatx4*)(bias + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      t[e] = __fadd_rn(t[e], b[e]);
+      if (relu) t[e] = fmaxf(t[e], 0.0f);
+    }
+    *(floatx4*)(out + n) = t;
+  }
+}
+
 struct ConvLayer {
-  int H, W, cin_shift, cout, kpad, nsplit, per;
+  int H, W, cin_shift, cout, kpad, nsplit, per, tn;
   size_t w_off, b_off;   // floats into the weight buffer
   int feat;              // >= 0: this layer's output is end point `feat`
   bool pool_after;
@@ -220,6 +260,7 @@ void disn_vgg_state_free(DisnCtx* ctx) {
 static const int VGG_BLOCKS[5][2] = {{2, 64}, {2, 128}, {3, 256}, {3, 512}, {3, 512}};
 static const int FC_K[3] = {7 * 7 * 512, 4096, 4096};
 static const int FC_N_DEFAULT[3] = {4096, 4096, 1024};
+static const int FC_ROWS[3] = {128, 32, 16};   // rows of W per partial sum (disn_vgg_forward)
 
 extern "C" int disn_vgg_set_weights(DisnCtx* ctx, int slot, const DisnVggWeights* w) {
   if (!ctx) return DISN_E_ARG;
@@ -253,10 +294,15 @@ extern "C" int disn_vgg_set_weights(DisnCtx* ctx, int slot, const DisnVggWeights
       c.feat = (l == VGG_BLOCKS[b][0] - 1) ? b : -1;
       c.pool_after = c.feat >= 0;
       // K split so that small maps still fill the chip; every split gets whole 16-k stages
-      const int tiles = ((hw * hw + GT - 1) / GT) * ((cout + GT - 1) / GT), stages = c.kpad / GK;
-      // (about three workgroups per CU: the kernel has no double buffering, co-resident workgroups hide its loads)
-      int want = tiles >= 3 * cu ? 1 : (3 * cu + tiles - 1) / tiles;
-      if (want > stages) want = stages;
+      c.tn = cout <= 64 ? 64 : GT;
+      const int tiles = ((hw * hw + GT - 1) / GT) * ((cout + c.tn - 1) / c.tn), stages = c.kpad / GK;
+      // (a few workgroups per CU: the kernel has no double buffering, co-resident workgroups hide its loads; but a split
+      // pays for a 64 KB tile of partial sums, so it gets at least VGG_MIN_STAGES stages)
+      static const int wg_per_cu = getenv("DISN_VGG_WG_PER_CU") ? atoi(getenv("DISN_VGG_WG_PER_CU")) : 2;
+      static const int min_stages = getenv("DISN_VGG_MIN_STAGES") ? atoi(getenv("DISN_VGG_MIN_STAGES")) : 4;
+      int want = tiles >= wg_per_cu * cu ? 1 : (wg_per_cu * cu + tiles - 1) / tiles;
+      if (want > stages / min_stages) want = stages / min_stages;
+      if (want < 1) want = 1;
       c.per = (stages + want - 1) / want;
       c.nsplit = (stages + c.per - 1) / c.per;
       if (c.nsplit > 1) part_floats = std::max(part_floats, (size_t)c.nsplit * hw * hw * cout);
@@ -287,8 +333,8 @@ extern "C" int disn_vgg_set_weights(DisnCtx* ctx, int slot, const DisnVggWeights
   const size_t act_floats = (size_t)224 * 224 * 64;
   DISN_TRY(disn_ensure(ctx, net.act[0], act_floats * sizeof(float)));
   DISN_TRY(disn_ensure(ctx, net.act[1], act_floats * sizeof(float)));
-  // fc partial sums share the buffer: fc6 splits 25088 rows into 196 ranges of 128
-  part_floats = std::max(part_floats, (size_t)196 * 4096);
+  // fc partial sums share the buffer: fc6 splits 25088 rows into 196 ranges of 128, fc7 4096 into 128, fc8 4096 into 512
+  for (int i = 0; i < 3; ++i) part_floats = std::max(part_floats, (size_t)((FC_K[i] + FC_ROWS[i] - 1) / FC_ROWS[i]) * fc_n[i]);
   DISN_TRY(disn_ensure(ctx, net.part, part_floats * sizeof(float)));
   DISN_TRY(disn_ensure(ctx, net.img224, (size_t)224 * 224 * 4 * sizeof(float)));
   DISN_TRY(disn_ensure(ctx, net.fcx[0], 4096 * sizeof(float)));
@@ -319,9 +365,13 @@ extern "C" int disn_vgg_forward(DisnCtx* ctx, int slot, const float* img, int im
     const int M = c.H * c.W;
     float* dst = c.feat >= 0 ? ((feat_maps && feat_maps[c.feat]) ? feat_maps[c.feat] : (float*)ctx->vgg->feats[c.feat].p)
                              : (float*)net.act[pp].p;
-    dim3 grid((c.cout + GT - 1) / GT, (M + GT - 1) / GT, c.nsplit);
-    k_conv3x3<<<grid, 256, 0, stream>>>(cur, Wd + c.w_off, Wd + c.b_off, c.nsplit > 1 ? (float*)net.part.p : dst, c.H, c.W,
-                                        c.cin_shift, c.cout, c.kpad, c.per, c.nsplit);
+    dim3 grid((c.cout + c.tn - 1) / c.tn, (M + GT - 1) / GT, c.nsplit);
+    if (c.tn == 64)
+      k_conv3x3<64><<<grid, 256, 0, stream>>>(cur, Wd + c.w_off, Wd + c.b_off, c.nsplit > 1 ? (float*)net.part.p : dst, c.H, c.W,
+                                              c.cin_shift, c.cout, c.kpad, c.per, c.nsplit);
+    else
+      k_conv3x3<GT><<<grid, 256, 0, stream>>>(cur, Wd + c.w_off, Wd + c.b_off, c.nsplit > 1 ? (float*)net.part.p : dst, c.H, c.W,
+                                              c.cin_shift, c.cout, c.kpad, c.per, c.nsplit);
     if (c.nsplit > 1) {
       const size_t total = (size_t)M * c.cout;
       k_sum_splits<<<(unsigned)((total / 4 + 255) / 256), 256, 0, stream>>>((const float*)net.part.p, c.nsplit, total, c.cout,
@@ -340,13 +390,14 @@ extern "C" int disn_vgg_forward(DisnCtx* ctx, int slot, const float* img, int im
   // cur = pool5 [7][7][512]; fc6 (7x7 VALID) + ReLU, fc7 + ReLU (dropout is the identity at inference), fc8 linear
   const int fc_n[3] = {FC_N_DEFAULT[0], FC_N_DEFAULT[1], FC_N_DEFAULT[2]};
   for (int i = 0; i < 3; ++i) {
-    const int K = FC_K[i], N = fc_n[i], rows = 128, ns = (K + rows - 1) / rows;
+    // row ranges sized so that every layer puts >= 512 workgroups on the chip (fc6: 196 ranges of 128 rows x 4 column
+    // blocks; fc7: 128 x 4; fc8: 512 x 1)
+    const int K = FC_K[i], N = fc_n[i], rows = FC_ROWS[i], ns = (K + rows - 1) / rows;
     dim3 grid((N / 4 + 255) / 256, ns);
     k_fc_partial<<<grid, 256, 0, stream>>>(cur, Wd + net.fc_w_off[i], K, N, rows, (float*)net.part.p);
     float* dst = i == 2 ? global_feat : (float*)net.fcx[i].p;
     if (!dst) dst = (float*)net.fcx[0].p;   // i == 2 without an output pointer: end points only
-    k_sum_splits<<<(N / 4 + 255) / 256, 256, 0, stream>>>((const float*)net.part.p, ns, (size_t)N, N, Wd + net.fc_b_off[i],
-                                                          i < 2 ? 1 : 0, dst);
+    k_sum_splits_fc<<<(N + 127) / 128, 256, 0, stream>>>((const float*)net.part.p, ns, N, Wd + net.fc_b_off[i], i < 2 ? 1 : 0, dst);
     cur = dst;
   }
   DISN_HIP(ctx, hipGetLastError());
