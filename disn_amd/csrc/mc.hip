@@ -3,14 +3,14 @@
 // demo/demo.py:355-369; algorithm: SURVEY.md Appendix B).
 //
 // HBM-bound scan/compaction.  Pipeline (all on the caller's stream):
-//   mc_classify   per grid point: voxel sub-table id + 3 edge-slot flags
-//                 -> info[P] (u16), per-block counters
-//   mc_scan       one workgroup: exclusive scan of the block counters,
-//                 per-layer centre offsets, totals
-//   mc_vertices   block scan of the slot flags -> vbase[P] (u32) and the edge
-//                 vertices, already in the reference's key order
-//   mc_triangles  block scan of triangle/centre counts -> triangles with final
-//                 indices (smallest first) + centre vertices
+//   mc_classify_walk  per grid point: 3 edge-slot flags + "voxel emits" -> info (u8), the voxel's sub-table
+//                     id -> sub (u16, surface only), per-tile counters
+//   mc_scan_tiles,    two-level exclusive scan of the tile counters, per-layer centre offsets, totals,
+//   mc_scan           lists of the tiles that own anything
+//   mc_vertices       wave scan of the slot flags -> vbase (u32, surface only) and the edge
+//                     vertices, already in the reference's key order
+//   mc_tri_records,   wave scan of triangle/centre counts -> one record per triangle, then one lane per
+//   mc_tri_finish     triangle: final indices (smallest first) + centre vertices
 //   tri_sort_*    LSD radix sort on the first index + run ordering (8-bit digits: histogram, per-digit row scan,
 //                 stable scatter) -> lexicographic order
 // Algorithmic bytes: 4 B/grid point + 24 B/vertex + 12 B/triangle.
@@ -55,18 +55,22 @@ __device__ __forceinline__ unsigned fdiv(unsigned p, const FastDiv& f) {
 
 struct Dims {
   int nx, ny, nz;
-  unsigned sxy;   // nx*ny
+  unsigned sxy;   // nx*ny: the caller's grid (sdf index p = (k ny + j) nx + i)
   unsigned P;     // nx*ny*nz
+  int pitch;      // nx rounded up to a multiple of 4: row length of the per-point arrays (index q, see below)
+  unsigned sxyq;  // pitch*ny
+  unsigned Q;     // pitch*ny*nz
   int own0, own1;
   int z_offset;
   float iso;
-  FastDiv dnx, dny;
+  FastDiv dpitch, dny;
 };
-__device__ __forceinline__ void point_ijk(const Dims& d, unsigned p, int& i, int& j, int& k) {
-  unsigned q = fdiv(p, d.dnx);
-  i = (int)(p - q * (unsigned)d.nx);
-  unsigned kk = fdiv(q, d.dny);
-  j = (int)(q - kk * (unsigned)d.ny);
+// grid coordinates of entry q of the per-point arrays
+__device__ __forceinline__ void point_ijk(const Dims& d, unsigned q, int& i, int& j, int& k) {
+  unsigned r = fdiv(q, d.dpitch);
+  i = (int)(q - r * (unsigned)d.pitch);
+  unsigned kk = fdiv(r, d.dny);
+  j = (int)(r - kk * (unsigned)d.ny);
   k = (int)kk;
 }
 
@@ -207,198 +211,40 @@ __device__ __forceinline__ unsigned point_flags_code(const float* __restrict__ s
   return flags;
 }
 
-// A tile = TILE consecutive points (the unit of the per-tile counters); a thread takes ITEMS = 4
-// consecutive points of it, so that the four voxels share their 20 corner values (instead of 32 loads)
-// and one index decomposition.  A workgroup takes CLS_TILES consecutive tiles and issues the loads of
-// all of them before using any: the kernel is bound by memory latency, not by bandwidth or ALU.
-// Voxels whose corners differ in sign are rare (the surface) but their sub-table lookup (face / interior
-// tests, B.3) is long: they are queued in LDS and classified by a dense set of lanes in a second phase,
-// instead of dragging whole waves through the long path once per point.
-constexpr int CLS_TILES = 1;
-typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte aligned address
-__global__ __launch_bounds__(BLK) void mc_classify(const float* __restrict__ sdf, Dims d, uint16_t* __restrict__ info,
-                                                    unsigned* __restrict__ bsum, unsigned nb,
-                                                    unsigned* __restrict__ layer_centre) {
-  __shared__ unsigned lcnt[CLS_TILES][NCNT];
-  __shared__ unsigned queue[CLS_TILES * TILE];
-  __shared__ unsigned short qsub[CLS_TILES * TILE];
-  __shared__ unsigned qn;
-  if (threadIdx.x == 0) qn = 0;
-  if (threadIdx.x < CLS_TILES * NCNT) (&lcnt[0][0])[threadIdx.x] = 0;
-  __syncthreads();
-  // per point: bits 0..2 edge flags, bit 3 plane below own0, bit 4 plane owned, bit 5 point exists
-  unsigned char meta[CLS_TILES][ITEMS];
-  short slot[CLS_TILES][ITEMS];
-  float raw[CLS_TILES][4][ITEMS + 1];
-  int ii[CLS_TILES], jj[CLS_TILES], kk[CLS_TILES];
-  bool interior[CLS_TILES];
-  // phase 0: issue the loads of every interior run
-#pragma unroll
-  for (int r = 0; r < CLS_TILES; ++r) {
-    const unsigned p0 = (blockIdx.x * CLS_TILES + r) * TILE + threadIdx.x * ITEMS;
-    interior[r] = false;
-    ii[r] = jj[r] = kk[r] = 0;
-    if (p0 < d.P) {
-      point_ijk(d, p0, ii[r], jj[r], kk[r]);
-      interior[r] = ii[r] + ITEMS < d.nx && jj[r] < d.ny - 1 && kk[r] < d.nz - 1;
-    }
-    if (interior[r]) {
-      // rows (j,k) (j+1,k) (j,k+1) (j+1,k+1), x = i .. i+4: one 16-byte load per row (rows are only
-      // 4-byte aligned: nx is odd) + the fifth value
-      const float* row[4] = {sdf + p0, sdf + p0 + d.nx, sdf + p0 + d.sxy, sdf + p0 + d.sxy + d.nx};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4u v = *(const float4u*)row[q];
-        raw[r][q][0] = v[0]; raw[r][q][1] = v[1]; raw[r][q][2] = v[2]; raw[r][q][3] = v[3];
-        raw[r][q][ITEMS] = row[q][ITEMS];
-      }
-    }
-  }
-  // phase 1: flags and corner codes; surface voxels go to the queue (unrolled by hand: the register
-  // arrays must keep compile-time indices)
-  auto phase1 = [&](auto rc) {
-    constexpr int r = decltype(rc)::value;
-    const unsigned p0 = (blockIdx.x * CLS_TILES + r) * TILE + threadIdx.x * ITEMS;
-#pragma unroll
-    for (int t = 0; t < ITEMS; ++t) { meta[r][t] = 0; slot[r][t] = -1; }
-    if (p0 >= d.P) return;
-    int i = ii[r], j = jj[r], k = kk[r];
-    if (interior[r]) {
-      float c5[4][ITEMS + 1];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int t = 0; t <= ITEMS; ++t) {
-          float v = __fsub_rn(raw[r][q][t], d.iso);   // B.1
-          c5[q][t] = v == 0.0f ? FLT_EPSILON : v;
-        }
-      const unsigned own = 32u | (k < d.own0 ? 8u : 0u) | ((k >= d.own0 && k < d.own1) ? 16u : 0u);
-#pragma unroll
-      for (int t = 0; t < ITEMS; ++t) {
-        const float c[8] = {c5[0][t], c5[0][t + 1], c5[1][t + 1], c5[1][t], c5[2][t], c5[2][t + 1], c5[3][t + 1], c5[3][t]};
-        unsigned code;
-        unsigned fl = point_flags_code(sdf, d, i + t, j, k, c, true, true, true, &code);
-        meta[r][t] = (unsigned char)(fl | own);
-        if (code != 0 && code != 255) {
-          slot[r][t] = (short)atomicAdd(&qn, 1u);
-          queue[slot[r][t]] = p0 + t;
-        }
-      }
-    } else {
-      // run touching a grid boundary (or the end of the grid): point by point
-#pragma unroll
-      for (int t = 0; t < ITEMS; ++t) {
-        const unsigned p = p0 + t;
-        if (p >= d.P) break;
-        const bool hx = i < d.nx - 1, hy = j < d.ny - 1, hz = k < d.nz - 1;
-        float c[8];
-        c[0] = cval(sdf, p, d.iso);
-        c[1] = hx ? cval(sdf, p + 1, d.iso) : 1.0f;
-        c[3] = hy ? cval(sdf, p + d.nx, d.iso) : 1.0f;
-        c[4] = hz ? cval(sdf, p + d.sxy, d.iso) : 1.0f;
-        if (hx && hy && hz) {
-          c[2] = cval(sdf, p + 1 + d.nx, d.iso);
-          c[5] = cval(sdf, p + d.sxy + 1, d.iso);
-          c[6] = cval(sdf, p + d.sxy + 1 + d.nx, d.iso);
-          c[7] = cval(sdf, p + d.sxy + d.nx, d.iso);
-        } else {
-          c[2] = c[5] = c[6] = c[7] = 1.0f;
-        }
-        unsigned code;
-        unsigned fl = point_flags_code(sdf, d, i, j, k, c, hx, hy, hz, &code);
-        meta[r][t] = (unsigned char)(fl | 32u | (k < d.own0 ? 8u : 0u) | ((k >= d.own0 && k < d.own1) ? 16u : 0u));
-        if (code != 0 && code != 255) {
-          slot[r][t] = (short)atomicAdd(&qn, 1u);
-          queue[slot[r][t]] = p;
-        }
-        if (++i == d.nx) {
-          i = 0;
-          if (++j == d.ny) { j = 0; ++k; }
-        }
-      }
-    }
-  };
-  phase1(std::integral_constant<int, 0>{});
-  if constexpr (CLS_TILES > 1) phase1(std::integral_constant<int, 1 % CLS_TILES>{});
-  if constexpr (CLS_TILES > 2) phase1(std::integral_constant<int, 2 % CLS_TILES>{});
-  if constexpr (CLS_TILES > 3) phase1(std::integral_constant<int, 3 % CLS_TILES>{});
-  static_assert(CLS_TILES <= 4, "phase1 is invoked once per tile");
-  __syncthreads();
-  // phase 2: the queued voxels (all of them have their 8 corners inside the grid)
-  for (unsigned e = threadIdx.x; e < qn; e += BLK) {
-    float c[8];
-    load_corners(sdf, d, queue[e], c);
-    qsub[e] = (unsigned short)classify(c);
-  }
-  __syncthreads();
-  // phase 3: owners assemble info and the counters (0 E_all, 1 T_own, 2 C_own, 3 E_low, 4 E_own)
-#pragma unroll
-  for (int r = 0; r < CLS_TILES; ++r) {
-    const unsigned p0 = (blockIdx.x * CLS_TILES + r) * TILE + threadIdx.x * ITEMS;
-    if (p0 >= d.P) continue;
-    unsigned cnt[NCNT] = {0, 0, 0, 0, 0};
-    unsigned short out[ITEMS];
-#pragma unroll
-    for (int t = 0; t < ITEMS; ++t) {
-      const unsigned m = meta[r][t], fl = m & 7u;
-      const unsigned sub = slot[r][t] >= 0 ? (unsigned)qsub[slot[r][t]] : NOSUB;
-      out[t] = (unsigned short)(sub | (fl << 10));
-      const unsigned ne = __popc(fl);
-      cnt[0] += ne;
-      if (m & 8u) cnt[3] += ne;
-      if (m & 16u) {
-        cnt[4] += ne;
-        if (sub != NOSUB) {
-          const unsigned char* st = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub]];
-          cnt[1] += st[0] / 3;
-          if (st[1]) {
-            cnt[2] += 1;
-            int i, j, k;
-            point_ijk(d, p0 + t, i, j, k);
-            atomicAdd(&layer_centre[k], 1u);
-          }
-        }
-      }
-    }
-    if (interior[r]) {
-      uint2 pk;
-      pk.x = out[0] | ((unsigned)out[1] << 16);
-      pk.y = out[2] | ((unsigned)out[3] << 16);
-      *(uint2*)(info + p0) = pk;   // p0 is a multiple of 4
-    } else {
-#pragma unroll
-      for (int t = 0; t < ITEMS; ++t)
-        if (meta[r][t] & 32u) info[p0 + t] = out[t];
-    }
-#pragma unroll
-    for (int n = 0; n < NCNT; ++n)
-      if (cnt[n]) atomicAdd(&lcnt[r][n], cnt[n]);   // almost always nothing to add
-  }
-  __syncthreads();
-  if (threadIdx.x < CLS_TILES * NCNT) {
-    const unsigned tile = blockIdx.x * CLS_TILES + threadIdx.x / NCNT;
-    if (tile < nb) bsum[(size_t)tile * NCNT + threadIdx.x % NCNT] = (&lcnt[0][0])[threadIdx.x];
-  }
+// ---- per-point arrays: index space q -------------------------------------
+// The caller's grid has rows of nx values (nx = sdf_res + 1 is odd); the arrays this file keeps per grid point --
+// info (1 byte), sub (2 bytes, sparse), vbase (4 bytes, sparse) -- have rows of `pitch` = nx rounded up to a multiple
+// of 4 entries, so that the classifier's runs of four points are whole aligned words: q = (k ny + j) pitch + i.
+// Pad entries (nx <= i < pitch) hold 0 and own nothing.  q grows with the reference's vertex key, so ranks taken
+// in q order are ranks in key order.  A TILE = 1024 consecutive q (the unit of the per-tile counters).
+//   info[q]  bits 0..2: edge slots (x, y, z) owned by the point; bits 3..6: triangles its voxel emits (0..12);
+//            bit 7: the voxel has a centre vertex -- everything the scans need, without a table look-up
+//   sub[q]   sub-table id of the voxel, written only where the voxel emits
+//   vbase[q] rank of the point's first edge slot, written only where a slot exists
+constexpr unsigned INFO_NT_SHIFT = 3, INFO_NT_MASK = 15u, INFO_CENTRE_SHIFT = 7;
+__device__ __forceinline__ unsigned sdf_index(const Dims& d, int i, int j, int k) {
+  return (unsigned)k * d.sxy + (unsigned)j * (unsigned)d.nx + (unsigned)i;
 }
 
-// ---- mc_classify_walk: the same outputs (info, per-tile counters, centres per layer) with every grid value
-// fetched about once and almost no arithmetic away from the surface.
-// mc_classify's linear tiles read a value from four places (its row, the row before, and both in the plane before),
-// which round-robin dispatch spreads over the XCDs (3.9x the grid in fabric traffic at sdf_res 1024), and spend
-// ~100 VALU instructions on every point.  Here a thread owns a column of 4 x 4 points (4 consecutive x, 4
-// consecutive rows) and walks L planes upwards: per step it loads the 5 x 5 values of the next plane above its
-// points (two planes ahead of their use, so two loads are in flight per thread), 1.25 x (L+1)/L of the grid in
-// total (the fifth value of a row is the next thread's first: the same cache line).  A step whose 50 values
-// (this plane and the one above) all lie on one side of the iso value, none of them within 2^-60 of it -- no sign
-// change, no product that could underflow (B.9) -- owns no vertex and no triangle: it is recognised with a
-// min / max over the new plane (the shift v - iso is monotonic in v) and only writes its 16 "nothing here"
-// entries.  The other steps -- the surface, a few lanes of a wave at a time -- are handed to the whole wave:
-// four such lanes' 4 x 4 points make 64 work items, each of which reads its corners again (cache hits) and takes
-// the per-point path of the specification (edge flags B.4 / B.9, corner code, sub-table lookup B.3).  Counters go
-// straight to the per-tile sums with global atomics (bsum and layer_centre start at zero): they fire only next
-// to the surface.
+// ---- mc_classify_walk: info, per-tile counters and centres per layer with every grid value fetched about once
+// and almost no arithmetic away from the surface.
+// A thread owns a column of 4 x 4 points (4 consecutive x, 4 consecutive rows) and walks L planes upwards: per
+// step it loads the 5 x 5 values of the next plane above its points (two planes ahead of their use, so two loads
+// are in flight per thread), 1.25 x (L+1)/L of the grid in total (the fifth value of a row is the next thread's
+// first: the same cache line).  A step whose 50 values (this plane and the one above) all lie on one side of the
+// iso value, none of them within 2^-60 of it -- no sign change, no product that could underflow (B.9) -- owns no
+// vertex and no triangle: it is recognised with a min / max over the new plane (the shift v - iso is monotonic
+// in v) and only writes its 16 "nothing here" bytes, one aligned word per row.  The other steps -- the surface, a
+// few lanes of a wave at a time -- are handed to the whole wave: four such lanes' 4 x 4 points make 64 work
+// items, each of which reads its corners again (cache hits) and takes the per-point path of the specification
+// (edge flags B.4 / B.9, corner code, sub-table lookup B.3).  Counters go straight to the per-tile sums with
+// global atomics (bsum and layer_centre start at zero): they fire only next to the surface.
+// (Rounds 1-2 classified linear tiles of 1024 points, ~100 VALU instructions per point and 3.9x the grid in fabric
+// traffic at sdf_res 1024; round 3 walked, but wrote 2-byte entries on the grid's own odd row length: ten
+// partial-line stores per quiet step.)
 constexpr int WROWS = 4;
 constexpr float WALK_TINY = 8.67361737988403547e-19f;   // 2^-60: products of larger values cannot underflow
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte aligned address
 
 // raw values of plane k above the column (x0.., j0..); entries outside the grid copy `fill` (an existing value of
 // the column: neutral for the min / max test)
@@ -435,11 +281,12 @@ __device__ __forceinline__ void walk_minmax(const float (&v)[WROWS + 1][ITEMS + 
   mx = fmaxf(fmaxf(b[0], b[1]), fmaxf(fmaxf(b[2], b[3]), b[4]));
 }
 
-// one grid point by the book (any position, boundary included): info entry and counters
+// one grid point by the book (any position, boundary included): info entry, sub-table id and counters
 __device__ __forceinline__ void walk_point(const float* __restrict__ sdf, const Dims& d, int i, int j, int k,
-                                           uint16_t* __restrict__ info, unsigned* __restrict__ bsum,
-                                           unsigned* __restrict__ layer_centre) {
-  const unsigned p = (unsigned)k * d.sxy + (unsigned)j * d.nx + (unsigned)i;
+                                           uint8_t* __restrict__ info, uint16_t* __restrict__ subs,
+                                           unsigned* __restrict__ bsum, unsigned* __restrict__ layer_centre) {
+  const unsigned p = sdf_index(d, i, j, k);
+  const unsigned q = (unsigned)k * d.sxyq + (unsigned)j * (unsigned)d.pitch + (unsigned)i;
   const bool hx = i < d.nx - 1, hy = j < d.ny - 1, hz = k < d.nz - 1;
   float c[8];
   c[0] = cval(sdf, p, d.iso);
@@ -457,28 +304,35 @@ __device__ __forceinline__ void walk_point(const float* __restrict__ sdf, const 
   unsigned code;
   const unsigned fl = point_flags_code(sdf, d, i, j, k, c, hx, hy, hz, &code);
   const unsigned sub = (code != 0 && code != 255) ? classify(c) : (unsigned)NOSUB;
-  info[p] = (unsigned short)(sub | (fl << 10));
+  unsigned nt = 0, nc = 0;
+  if (sub != NOSUB) {
+    const unsigned char* st = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub]];
+    nt = st[0] / 3;   // 1..12
+    nc = st[1];
+    subs[q] = (uint16_t)sub;
+  }
+  info[q] = (uint8_t)(fl | (nt << INFO_NT_SHIFT) | (nc << INFO_CENTRE_SHIFT));
   const bool low = k < d.own0, owned = k >= d.own0 && k < d.own1;
-  unsigned* bs = bsum + (size_t)(p / TILE) * NCNT;
+  unsigned* bs = bsum + (size_t)(q / TILE) * NCNT;
   if (fl) {
     const unsigned ne = __popc(fl);
     atomicAdd(&bs[0], ne);
     if (low) atomicAdd(&bs[3], ne);
     if (owned) atomicAdd(&bs[4], ne);
   }
-  if (owned && sub != NOSUB) {
-    const unsigned char* st = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub]];
-    atomicAdd(&bs[1], (unsigned)(st[0] / 3));
-    if (st[1]) {
+  if (owned && nt) {
+    atomicAdd(&bs[1], nt);
+    if (nc) {
       atomicAdd(&bs[2], 1u);
       atomicAdd(&layer_centre[k], 1u);
     }
   }
 }
 
-__global__ __launch_bounds__(BLK) void mc_classify_walk(const float* __restrict__ sdf, Dims d, uint16_t* __restrict__ info,
-                                                         unsigned* __restrict__ bsum, unsigned* __restrict__ layer_centre,
-                                                         int nq, int ng, int L, FastDiv dnq, FastDiv dng, unsigned nthreads) {
+__global__ __launch_bounds__(BLK) void mc_classify_walk(const float* __restrict__ sdf, Dims d, uint8_t* __restrict__ info,
+                                                         uint16_t* __restrict__ subs, unsigned* __restrict__ bsum,
+                                                         unsigned* __restrict__ layer_centre, int nq, int ng, int L,
+                                                         FastDiv dnq, FastDiv dng, unsigned nthreads) {
   const unsigned tid = blockIdx.x * BLK + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool valid = tid < nthreads;
@@ -486,14 +340,13 @@ __global__ __launch_bounds__(BLK) void mc_classify_walk(const float* __restrict_
   if (valid) {
     const unsigned t2 = fdiv(tid, dnq);
     const unsigned ch = fdiv(t2, dng);
-    x0 = (int)(tid - t2 * (unsigned)nq) * ITEMS;
+    x0 = (int)(tid - t2 * (unsigned)nq) * ITEMS;   // nq = pitch / 4: the runs tile the padded row exactly
     j0 = (int)(t2 - ch * (unsigned)ng) * WROWS;
     k0 = (int)ch * L;
     k1 = min(d.nz, k0 + L);
   }
   const float fill = sdf[valid ? (size_t)k0 * d.sxy + (size_t)j0 * d.nx + x0 : 0];
-  const bool fullx = x0 + ITEMS <= d.nx;   // all four points of a row exist
-  __shared__ unsigned queue[BLK / 64][128];   // per wave: surface points waiting for the long path
+  __shared__ unsigned queue[BLK / 64][128];   // per wave: surface points (q) waiting for the long path
   volatile unsigned* myq = queue[threadIdx.x >> 6];
   unsigned qn = 0;                             // wave-uniform
   float hi[WROWS + 1][ITEMS + 1], nn[WROWS + 1][ITEMS + 1];
@@ -514,27 +367,11 @@ __global__ __launch_bounds__(BLK) void mc_classify_walk(const float* __restrict_
     const bool quiet = cmin > WALK_TINY || cmax < -WALK_TINY;
 #endif
     if (alive && quiet) {
-      // 16 entries "no surface, no edge slot"; a row starts at any parity (nx is odd), so 4-byte stores only where aligned
-      const unsigned two = NOSUB | (NOSUB << 16);
+      // 16 entries "no surface, no edge slot" (pad columns included): one aligned word per row
+      const unsigned qrow = (unsigned)k * d.sxyq + (unsigned)j0 * (unsigned)d.pitch + (unsigned)x0;
 #pragma unroll
-      for (int r = 0; r < WROWS; ++r) {
-        if (j0 + r >= d.ny) break;
-        const unsigned prow = (unsigned)k * d.sxy + (unsigned)(j0 + r) * d.nx + (unsigned)x0;
-        if (fullx) {
-          if ((prow & 1u) == 0) {
-            *(unsigned*)(info + prow) = two;
-            *(unsigned*)(info + prow + 2) = two;
-          } else {
-            info[prow] = (unsigned short)NOSUB;
-            *(unsigned*)(info + prow + 1) = two;
-            info[prow + 3] = (unsigned short)NOSUB;
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < ITEMS; ++t)
-            if (x0 + t < d.nx) info[prow + t] = (unsigned short)NOSUB;
-        }
-      }
+      for (int r = 0; r < WROWS; ++r)
+        if (j0 + r < d.ny) *(unsigned*)(info + qrow + (unsigned)r * (unsigned)d.pitch) = 0u;
     }
     unsigned long long need = __ballot(alive && !quiet);
     while (need) {   // wave-uniform: four columns at a time, one of their 64 points per lane
@@ -551,27 +388,30 @@ __global__ __launch_bounds__(BLK) void mc_classify_walk(const float* __restrict_
       const int i = sx + (pt & 3), j = sj + (pt >> 2);
       // the point's own eight corners (those that exist) decide whether it is next to the surface at all
       bool active = false;
-      unsigned p = 0;
-      if (from >= 0 && i < d.nx && j < d.ny) {
-        p = (unsigned)sk * d.sxy + (unsigned)j * d.nx + (unsigned)i;
-        const unsigned ox = i < d.nx - 1 ? 1u : 0u, oy = j < d.ny - 1 ? (unsigned)d.nx : 0u, oz = sk < d.nz - 1 ? d.sxy : 0u;
-        const float a0 = sdf[p], a1 = sdf[p + ox], a2 = sdf[p + oy], a3 = sdf[p + ox + oy];
-        const float b0 = sdf[p + oz], b1 = sdf[p + oz + ox], b2 = sdf[p + oz + oy], b3 = sdf[p + oz + ox + oy];
-        const float mn = fminf(fminf(fminf(a0, a1), fminf(a2, a3)), fminf(fminf(b0, b1), fminf(b2, b3)));
-        const float mx = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
-        active = !(__fsub_rn(mn, d.iso) > WALK_TINY || __fsub_rn(mx, d.iso) < -WALK_TINY);
-        if (!active) info[p] = (unsigned short)NOSUB;
+      unsigned q = 0;
+      if (from >= 0 && j < d.ny) {   // i < pitch always
+        q = (unsigned)sk * d.sxyq + (unsigned)j * (unsigned)d.pitch + (unsigned)i;
+        if (i < d.nx) {
+          const unsigned p = sdf_index(d, i, j, sk);
+          const unsigned ox = i < d.nx - 1 ? 1u : 0u, oy = j < d.ny - 1 ? (unsigned)d.nx : 0u, oz = sk < d.nz - 1 ? d.sxy : 0u;
+          const float a0 = sdf[p], a1 = sdf[p + ox], a2 = sdf[p + oy], a3 = sdf[p + ox + oy];
+          const float b0 = sdf[p + oz], b1 = sdf[p + oz + ox], b2 = sdf[p + oz + oy], b3 = sdf[p + oz + ox + oy];
+          const float mn = fminf(fminf(fminf(a0, a1), fminf(a2, a3)), fminf(fminf(b0, b1), fminf(b2, b3)));
+          const float mx = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
+          active = !(__fsub_rn(mn, d.iso) > WALK_TINY || __fsub_rn(mx, d.iso) < -WALK_TINY);
+        }
+        if (!active) info[q] = 0;   // quiet point or pad column
       }
       // surface points collect in the wave's queue and take the long path 64 at a time
       const unsigned long long act = __ballot(active);
-      if (active) myq[qn + __popcll(act & ((1ull << lane) - 1ull))] = p;
+      if (active) myq[qn + __popcll(act & ((1ull << lane) - 1ull))] = q;
       qn += __popcll(act);
       if (qn >= 64) {
         const unsigned pq = myq[lane];
         const unsigned rest = lane < (int)(qn - 64) ? myq[64 + lane] : 0u;
         int qi, qj, qk;
         point_ijk(d, pq, qi, qj, qk);
-        walk_point(sdf, d, qi, qj, qk, info, bsum, layer_centre);
+        walk_point(sdf, d, qi, qj, qk, info, subs, bsum, layer_centre);
         if (lane < (int)(qn - 64)) myq[lane] = rest;
         qn -= 64;
       }
@@ -586,22 +426,47 @@ __global__ __launch_bounds__(BLK) void mc_classify_walk(const float* __restrict_
   if (lane < (int)qn) {   // what is left in the queue
     int qi, qj, qk;
     point_ijk(d, myq[lane], qi, qj, qk);
-    walk_point(sdf, d, qi, qj, qk, info, bsum, layer_centre);
+    walk_point(sdf, d, qi, qj, qk, info, subs, bsum, layer_centre);
   }
 }
 
 // Two-level exclusive scan of the per-tile counters.  Level 1, one workgroup per chunk of SCAN_CHUNK
 // tiles: boff[b][0..2] = prefix of (E_all, T_own, C_own) inside the chunk, csum[chunk][0..4] = chunk sums.
+// Also compacts the tiles the emit kernels have to visit: actn[0] / actn[1] = number of tiles with an edge slot /
+// with an owned triangle (both start at zero), their ids at act and act + nb.  A workgroup launched only to read
+// its counter and leave still costs its launch (a million of them at sdf_res 1024).  The order of a list does not
+// matter: every tile knows its own output positions.
 constexpr int SCAN_CHUNK = BLK * ITEMS;   // 1024 tiles
 __global__ __launch_bounds__(BLK) void mc_scan_tiles(const unsigned* __restrict__ bsum, unsigned nb,
-                                                     unsigned* __restrict__ boff, unsigned* __restrict__ csum) {
+                                                     unsigned* __restrict__ boff, unsigned* __restrict__ csum,
+                                                     unsigned* __restrict__ actn, unsigned* __restrict__ act) {
   __shared__ unsigned lds[BLK / 64];
+  __shared__ unsigned abase[2];
   const unsigned b0 = blockIdx.x * SCAN_CHUNK + threadIdx.x * ITEMS;
   unsigned v[ITEMS][NCNT];
 #pragma unroll
   for (int t = 0; t < ITEMS; ++t)
 #pragma unroll
     for (int n = 0; n < NCNT; ++n) v[t][n] = b0 + t < nb ? bsum[(size_t)(b0 + t) * NCNT + n] : 0u;
+  {
+    unsigned mine = 0;   // low half: tiles with slots, high half: tiles with owned triangles (<= 1024 per chunk)
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) mine += (v[t][0] != 0u ? 1u : 0u) | (v[t][1] != 0u ? 0x10000u : 0u);
+    unsigned tot;
+    const unsigned ex = block_excl_scan(mine, lds, &tot);
+    if (threadIdx.x == 0) {
+      abase[0] = (tot & 0xffffu) ? atomicAdd(&actn[0], tot & 0xffffu) : 0u;
+      abase[1] = (tot >> 16) ? atomicAdd(&actn[1], tot >> 16) : 0u;
+    }
+    __syncthreads();
+    unsigned* lv = act + abase[0] + (ex & 0xffffu);
+    unsigned* lt = act + (size_t)nb + abase[1] + (ex >> 16);
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+      if (v[t][0] != 0u) *lv++ = b0 + t;
+      if (v[t][1] != 0u) *lt++ = b0 + t;
+    }
+  }
 #pragma unroll
   for (int n = 0; n < NCNT; ++n) {
     unsigned s = 0;
@@ -621,13 +486,14 @@ __global__ __launch_bounds__(BLK) void mc_scan_tiles(const unsigned* __restrict_
 }
 
 // Level 2, one workgroup of 1024 threads over the chunk sums (nb = number of chunks).  boff[c][0..2] =
-// exclusive prefix of (E_all, T_own, C_own) over the chunks; totals[0..4] = sums of the five counters (u64);
-// layer[k] (in: centres of layer k) -> layer_asc[k] = centres in layers < k.
+// exclusive prefix of (E_all, T_own, C_own) over the chunks; totals[0..4] = sums of the five counters (u64),
+// totals[5..6] = lengths of the two tile lists; layer[k] (in: centres of layer k) -> layer_asc[k] = centres in layers < k.
 __global__ __launch_bounds__(1024) void mc_scan(const unsigned* __restrict__ bsum, unsigned nb, unsigned* __restrict__ boff,
                                                  unsigned long long* __restrict__ totals,
                                                  const unsigned* __restrict__ layer_centre, unsigned* __restrict__ layer_asc,
-                                                 int nz) {
+                                                 int nz, const unsigned* __restrict__ actn) {
   __shared__ unsigned long long part[1024];
+  if (threadIdx.x < 2) totals[NCNT + threadIdx.x] = actn[threadIdx.x];
   const unsigned chunk = (nb + 1023) / 1024;
   const unsigned b0 = threadIdx.x * chunk, b1 = min(nb, b0 + chunk);
   for (int n = 0; n < NCNT; ++n) {
@@ -684,6 +550,7 @@ struct EmitArgs {
   int* tris;
 };
 
+// p = sdf index of grid point (i, j, k)
 __device__ __forceinline__ void edge_position(const float* __restrict__ sdf, const Dims& d, const EmitArgs& a, int i, int j,
                                               int k, unsigned p, int dir, double* pos) {
   const unsigned stride = dir == 0 ? 1u : dir == 1 ? (unsigned)d.nx : d.sxy;
@@ -695,57 +562,70 @@ __device__ __forceinline__ void edge_position(const float* __restrict__ sdf, con
   pos[dir] = __dadd_rn(pos[dir], __ddiv_rn(__dmul_rn((double)ca, a.h[dir]), (double)diff));  // B.4
 }
 
-// info of the ITEMS consecutive points of a thread (0 past the end of the grid)
-__device__ __forceinline__ void load_info4(const uint16_t* __restrict__ info, const Dims& d, unsigned p0, unsigned* w) {
-  if (p0 + ITEMS <= d.P) {
-    uint2 pk = *(const uint2*)(info + p0);   // p0 is a multiple of 4
-    w[0] = pk.x & 0xffffu; w[1] = pk.x >> 16; w[2] = pk.y & 0xffffu; w[3] = pk.y >> 16;
+// The emit kernels: ONE WAVE per tile, no workgroup barrier.  A lane takes 16 consecutive entries of the tile (one
+// 16-byte load of info), a wave scan gives every lane its output positions, and the few entries that own
+// something -- the surface crosses a row of 1024 points a handful of times -- go through the wave's LDS queue to
+// a dense set of lanes.  (Round 3 ran a workgroup of 256 threads per tile: five barriers and a block scan for
+// four or five surface points.)
+constexpr int WPT = TILE / 64;   // entries per lane
+__device__ __forceinline__ void load_info16(const uint8_t* __restrict__ info, const Dims& d, unsigned q0, unsigned* w) {
+  if (q0 + WPT <= d.Q) {
+    const uint4 v = *(const uint4*)(info + q0);   // q0 is a multiple of 16
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
   } else {
 #pragma unroll
-    for (int t = 0; t < ITEMS; ++t) w[t] = p0 + t < d.P ? info[p0 + t] : (unsigned)NOSUB;
+    for (int c = 0; c < 4; ++c) {
+      w[c] = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (q0 + 4 * c + b < d.Q) w[c] |= (unsigned)info[q0 + 4 * c + b] << (8 * b);
+    }
   }
 }
 
-// boff = prefix inside the chunk of SCAN_CHUNK tiles, coff = prefix over the chunks
-__global__ __launch_bounds__(BLK) void mc_vertices(const float* __restrict__ sdf, Dims d, const uint16_t* __restrict__ info,
-                                                    const unsigned* __restrict__ bsum, const unsigned* __restrict__ boff,
-                                                    const unsigned* __restrict__ coff, unsigned* __restrict__ vbase, EmitArgs a) {
-  __shared__ unsigned lds[BLK / 64];
-  if (bsum[(size_t)blockIdx.x * NCNT + 0] == 0) return;   // no edge slot in this tile (most tiles): nothing to rank or emit
-  const unsigned p0 = blockIdx.x * TILE + threadIdx.x * ITEMS;
-  unsigned w[ITEMS], fl[ITEMS], ne = 0;
-  load_info4(info, d, p0, w);
+// boff = prefix inside the chunk of SCAN_CHUNK tiles, coff = prefix over the chunks; tiles = the tiles with edge slots
+__global__ __launch_bounds__(BLK) void mc_vertices(const float* __restrict__ sdf, Dims d, const uint8_t* __restrict__ info,
+                                                    const unsigned* __restrict__ boff, const unsigned* __restrict__ coff,
+                                                    unsigned* __restrict__ vbase, EmitArgs a, const unsigned* __restrict__ tiles,
+                                                    unsigned ntiles) {
+  // queue entry: position in the tile (10 bits) | flags << 10 | rank offset inside the tile << 13 (<= 3072)
+  __shared__ unsigned queue[BLK / 64][TILE];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned ti = blockIdx.x * (BLK / 64) + w;
+  if (ti >= ntiles) return;
+  const unsigned tile = tiles[ti];
+  const unsigned q0 = tile * TILE + lane * WPT;
+  unsigned wd[4];
+  load_info16(info, d, q0, wd);
+  unsigned mine = 0;   // low half: slots, high half: entries that own slots
 #pragma unroll
-  for (int t = 0; t < ITEMS; ++t) {
-    fl[t] = (w[t] >> 10) & 7u;
-    ne += __popc(fl[t]);
+  for (int c = 0; c < 4; ++c) {
+    const unsigned f = wd[c] & 0x07070707u;
+    mine += __popc(f) | (__popc((f | (f >> 1) | (f >> 2)) & 0x01010101u) << 16);
   }
-  unsigned tot;
-  unsigned vb = boff[(size_t)blockIdx.x * 3 + 0] + coff[(size_t)(blockIdx.x / SCAN_CHUNK) * 3 + 0] +
-                block_excl_scan(ne, lds, &tot);
-  // points that own slots are rare (the surface): queue them and let a dense set of lanes emit
-  __shared__ unsigned qp[TILE], qv[TILE];
-  __shared__ unsigned char qf[TILE];
-  __shared__ unsigned qn;
-  if (threadIdx.x == 0) qn = 0;
-  __syncthreads();
+  const unsigned inc = wave_incl_scan(mine, lane);
+  const unsigned ntot = __shfl(inc, 63, 64) >> 16;
+  unsigned vo = (inc - mine) & 0xffffu, e = (inc - mine) >> 16;
+  volatile unsigned* myq = queue[w];
+  if (mine) {
 #pragma unroll
-  for (int t = 0; t < ITEMS; ++t) {
-    if (fl[t]) {
-      const unsigned e = atomicAdd(&qn, 1u);
-      qp[e] = p0 + t;
-      qv[e] = vb;
-      qf[e] = (unsigned char)fl[t];
-      vb += __popc(fl[t]);
+    for (int b = 0; b < WPT; ++b) {
+      const unsigned fl = (wd[b >> 2] >> (8 * (b & 3))) & 7u;
+      if (fl) {
+        myq[e++] = (unsigned)(lane * WPT + b) | (fl << 10) | (vo << 13);
+        vo += __popc(fl);
+      }
     }
   }
-  __syncthreads();
-  for (unsigned e = threadIdx.x; e < qn; e += BLK) {
-    const unsigned p = qp[e], flags = qf[e], v0 = qv[e];
-    vbase[p] = v0;   // only slots that exist are ever looked up
+  const unsigned tbase = boff[(size_t)tile * 3 + 0] + coff[(size_t)(tile / SCAN_CHUNK) * 3 + 0];
+  for (unsigned x = lane; x < ntot; x += 64) {
+    const unsigned ent = myq[x];
+    const unsigned q = tile * TILE + (ent & 1023u), flags = (ent >> 10) & 7u, v0 = tbase + (ent >> 13);
+    vbase[q] = v0;   // only slots that exist are ever looked up
     int i, j, k;
-    point_ijk(d, p, i, j, k);
+    point_ijk(d, q, i, j, k);
     if (k < d.own0 || k >= d.own1) continue;
+    const unsigned p = sdf_index(d, i, j, k);
     unsigned long long out = (unsigned long long)a.c_own + (v0 - a.e_low);
 #pragma unroll
     for (int dir = 0; dir < 3; ++dir) {
@@ -762,70 +642,83 @@ __global__ __launch_bounds__(BLK) void mc_vertices(const float* __restrict__ sdf
   }
 }
 
-__global__ __launch_bounds__(BLK) void mc_triangles(const float* __restrict__ sdf, Dims d, const uint16_t* __restrict__ info,
-                                                     const unsigned* __restrict__ bsum, const unsigned* __restrict__ boff,
-                                                     const unsigned* __restrict__ coff, const unsigned* __restrict__ vbase,
-                                                     const unsigned* __restrict__ layer_asc, EmitArgs a) {
-  __shared__ unsigned lds[BLK / 64];
-  if (bsum[(size_t)blockIdx.x * NCNT + 1] == 0) return;   // no owned triangle (hence no centre vertex) in this tile
-  const unsigned p0 = blockIdx.x * TILE + threadIdx.x * ITEMS;
-  const unsigned own_lo = (unsigned)d.own0 * d.sxy, own_hi = (unsigned)d.own1 * d.sxy;   // owned layers as a point range
-  unsigned w[ITEMS], sub4[ITEMS], packed = 0;
-  load_info4(info, d, p0, w);
+// Triangles in two steps.  mc_tri_records (one wave per tile with owned triangles -- every centre vertex belongs to
+// one of them): wave scan of (triangles, centres) per entry, then every emitting voxel leaves one 12-byte RECORD per
+// triangle in the triangle's own slot of the output array: (q, sub-table id | triangle number << 10, centre rank).
+// mc_tri_finish (one LANE per triangle, all lanes busy): turns the record into the three final vertex indices in
+// place.  (Doing both per tile kept 4 or 5 lanes of a wave busy through a dozen dependent look-ups per triangle:
+// 1.2 of the 4.6 ms at sdf_res 1024.)
+__global__ __launch_bounds__(BLK) void mc_tri_records(Dims d, const uint8_t* __restrict__ info, const uint16_t* __restrict__ subs,
+                                                       const unsigned* __restrict__ boff, const unsigned* __restrict__ coff,
+                                                       int* __restrict__ tris, const unsigned* __restrict__ tiles,
+                                                       unsigned ntiles) {
+  const int lane = threadIdx.x & 63;
+  const unsigned ti = blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+  if (ti >= ntiles) return;
+  const unsigned tile = tiles[ti];
+  const unsigned q0 = tile * TILE + lane * WPT;
+  const unsigned own_lo = (unsigned)d.own0 * d.sxyq, own_hi = (unsigned)d.own1 * d.sxyq;   // owned layers as a range of q
+  unsigned wd[4];
+  load_info16(info, d, q0, wd);
+  unsigned actmask = 0;   // bit b: entry b of this lane is an owned voxel that emits
+  unsigned packed = 0;    // triangles | centres << 16 of this lane's entries
 #pragma unroll
-  for (int t = 0; t < ITEMS; ++t) {
-    const unsigned p = p0 + t;
-    sub4[t] = (p >= own_lo && p < own_hi) ? (w[t] & NOSUB) : (unsigned)NOSUB;
-    if (sub4[t] != NOSUB) {
-      const unsigned char* s = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub4[t]]];
-      packed += (unsigned)(s[0] / 3) | ((unsigned)s[1] << 16);
+  for (int b = 0; b < WPT; ++b) {
+    const unsigned e = (wd[b >> 2] >> (8 * (b & 3))) & 0xffu;
+    if ((e >> INFO_NT_SHIFT) && q0 + b >= own_lo && q0 + b < own_hi) {
+      actmask |= 1u << b;
+      packed += ((e >> INFO_NT_SHIFT) & INFO_NT_MASK) | ((e >> INFO_CENTRE_SHIFT) << 16);
     }
   }
-  unsigned tot;
-  const unsigned ex = block_excl_scan(packed, lds, &tot);
-  const size_t ch = (size_t)(blockIdx.x / SCAN_CHUNK) * 3;
-  unsigned tb = boff[(size_t)blockIdx.x * 3 + 1] + coff[ch + 1] + (ex & 0xffffu);
-  unsigned cb = boff[(size_t)blockIdx.x * 3 + 2] + coff[ch + 2] + (ex >> 16);
-  // active voxels are rare (the surface): queue them and let a dense set of lanes emit
-  __shared__ unsigned qp[TILE], qt[TILE], qc[TILE];
-  __shared__ unsigned short qs[TILE];
-  __shared__ unsigned qn;
-  if (threadIdx.x == 0) qn = 0;
-  __syncthreads();
+  unsigned off = wave_incl_scan(packed, lane) - packed;
+  if (!actmask) return;
+  const size_t ch = (size_t)(tile / SCAN_CHUNK) * 3;
+  const unsigned tbase = boff[(size_t)tile * 3 + 1] + coff[ch + 1];
+  const unsigned cbase = boff[(size_t)tile * 3 + 2] + coff[ch + 2];
 #pragma unroll
-  for (int t = 0; t < ITEMS; ++t) {
-    if (sub4[t] != NOSUB) {
-      const unsigned char* st = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub4[t]]];
-      const unsigned e = atomicAdd(&qn, 1u);
-      qp[e] = p0 + t; qt[e] = tb; qc[e] = cb; qs[e] = (unsigned short)sub4[t];
-      tb += st[0] / 3;
-      cb += st[1];
+  for (int b = 0; b < WPT; ++b) {
+    if (!(actmask >> b & 1u)) continue;
+    const unsigned e = (wd[b >> 2] >> (8 * (b & 3))) & 0xffu;
+    const unsigned nt = (e >> INFO_NT_SHIFT) & INFO_NT_MASK, nc = e >> INFO_CENTRE_SHIFT;
+    const unsigned sub = subs[q0 + b];
+    int* rec = tris + 3 * (size_t)(tbase + (off & 0xffffu));
+    for (unsigned tt = 0; tt < nt; ++tt) {
+      rec[3 * tt + 0] = (int)(q0 + b);
+      rec[3 * tt + 1] = (int)(sub | (tt << 10));
+      rec[3 * tt + 2] = (int)(cbase + (off >> 16));
     }
+    off += nt | (nc << 16);
   }
-  __syncthreads();
-  for (unsigned qe = threadIdx.x; qe < qn; qe += BLK) {
-    const unsigned p = qp[qe], sub = qs[qe];
-    unsigned tb = qt[qe], cb = qc[qe];
+}
+
+__global__ __launch_bounds__(BLK) void mc_tri_finish(const float* __restrict__ sdf, Dims d, const uint8_t* __restrict__ info,
+                                                      const unsigned* __restrict__ vbase, const unsigned* __restrict__ layer_asc,
+                                                      EmitArgs a, unsigned ntri) {
+  const unsigned t = blockIdx.x * BLK + threadIdx.x;
+  if (t >= ntri) return;
+  int* o = a.tris + 3 * (size_t)t;
+  const unsigned q = (unsigned)o[0], w1 = (unsigned)o[1], cb = (unsigned)o[2];
+  const unsigned sub = w1 & 1023u, tt = w1 >> 10;
+  const unsigned char* s = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub]];
+  long long centre_idx = -1;
+  if (s[1]) {
+    // B.5/B.6: centres ordered by descending k, then ascending (j,i)
     int i, j, k;
-    point_ijk(d, p, i, j, k);
-    const unsigned char* s = &DISN_MC_TRI[DISN_MC_SUB_OFFSET[sub]];
-    const unsigned nt = s[0] / 3, nc = s[1];
-    // index of each of the 12 edges' vertices (only those referenced are read)
-    long long centre_idx = -1;
-    if (nc) {
-      // B.5/B.6: centres ordered by descending k, then ascending (j,i)
-      unsigned in_layer = cb - layer_asc[k];
-      unsigned desc = (a.c_own - layer_asc[k + 1]) + in_layer;
-      centre_idx = (long long)a.centre_base + desc;
+    point_ijk(d, q, i, j, k);
+    const unsigned in_layer = cb - layer_asc[k];
+    const unsigned desc = (a.c_own - layer_asc[k + 1]) + in_layer;
+    centre_idx = (long long)a.centre_base + desc;
+    if (tt == 0) {   // the voxel's first triangle also writes the centre vertex: mean of ALL crossed edges (B.5)
+      const unsigned p = sdf_index(d, i, j, k);
       double acc[3] = {0, 0, 0};
       int n = 0;
       for (int e = 0; e < 12; ++e) {
         int ca = DISN_MC_EDGE[e][0], dir = DISN_MC_EDGE[e][2];
         int di = DISN_MC_CORNER[ca][0], dj = DISN_MC_CORNER[ca][1], dk = DISN_MC_CORNER[ca][2];
-        unsigned pa = p + di + dj * d.nx + dk * d.sxy;
-        if (!((info[pa] >> 10) >> dir & 1)) continue;
+        unsigned qa = q + di + dj * d.pitch + dk * d.sxyq;
+        if (!(info[qa] >> dir & 1)) continue;
         double pos[3];
-        edge_position(sdf, d, a, i + di, j + dj, k + dk, pa, dir, pos);
+        edge_position(sdf, d, a, i + di, j + dj, k + dk, p + di + dj * d.nx + dk * d.sxy, dir, pos);
         acc[0] = __dadd_rn(acc[0], pos[0]);
         acc[1] = __dadd_rn(acc[1], pos[1]);
         acc[2] = __dadd_rn(acc[2], pos[2]);
@@ -836,30 +729,39 @@ __global__ __launch_bounds__(BLK) void mc_triangles(const float* __restrict__ sd
       a.verts[3 * (size_t)desc + 2] = __ddiv_rn(acc[2], (double)n);
       if (a.keys) a.keys[desc] = -(long long)(k + d.z_offset) * d.sxy + (long long)j * d.nx + i - 1;
     }
-    for (unsigned tt = 0; tt < nt; ++tt) {
-      int v[3];
+  }
+  int v[3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        int e = s[2 + 3 * tt + q];
-        if (e == 12) {
-          v[q] = (int)centre_idx;
-        } else {
-          int ca = DISN_MC_EDGE[e][0], dir = DISN_MC_EDGE[e][2];
-          unsigned pa = p + DISN_MC_CORNER[ca][0] + DISN_MC_CORNER[ca][1] * d.nx + DISN_MC_CORNER[ca][2] * d.sxy;
-          unsigned fl = (unsigned)(info[pa] >> 10);
-          v[q] = (int)(a.edge_base + (vbase[pa] - a.e_low) + __popc(fl & ((1u << dir) - 1u)));
-        }
-      }
-      int m = 0;  // B.6: rotate, smallest index first
-      if (v[1] < v[m]) m = 1;
-      if (v[2] < v[m]) m = 2;
-      int r0 = v[m], r1 = v[m == 2 ? 0 : m + 1], r2 = v[m == 0 ? 2 : m - 1];
-      int* o = a.tris + 3 * (size_t)(tb + tt);
-      o[0] = r0;
-      o[1] = r1;
-      o[2] = r2;
+  for (int c = 0; c < 3; ++c) {
+    int e = s[2 + 3 * tt + c];
+    if (e == 12) {
+      v[c] = (int)centre_idx;
+    } else {
+      int ca = DISN_MC_EDGE[e][0], dir = DISN_MC_EDGE[e][2];
+      unsigned qa = q + DISN_MC_CORNER[ca][0] + DISN_MC_CORNER[ca][1] * d.pitch + DISN_MC_CORNER[ca][2] * d.sxyq;
+      unsigned fl = (unsigned)info[qa] & 7u;
+      v[c] = (int)(a.edge_base + (vbase[qa] - a.e_low) + __popc(fl & ((1u << dir) - 1u)));
     }
   }
+  int m = 0;  // B.6: rotate, smallest index first
+  if (v[1] < v[m]) m = 1;
+  if (v[2] < v[m]) m = 2;
+  const int r0 = v[m], r1 = v[m == 2 ? 0 : m + 1], r2 = v[m == 0 ? 2 : m - 1];
+  o[0] = r0;
+  o[1] = r1;
+  o[2] = r2;
+}
+
+// the round-2 view of the classification for the parity tests: out[p] = sub-table id (0x3ff = none) | flags << 10
+__global__ void mc_export_info(Dims d, const uint8_t* __restrict__ info, const uint16_t* __restrict__ subs,
+                               uint16_t* __restrict__ out) {
+  const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= d.Q) return;
+  int i, j, k;
+  point_ijk(d, q, i, j, k);
+  if (i >= d.nx) return;
+  const unsigned b = info[q];
+  out[sdf_index(d, i, j, k)] = (uint16_t)(((b >> INFO_NT_SHIFT) ? (unsigned)subs[q] : (unsigned)NOSUB) | ((b & 7u) << 10));
 }
 
 // ---- LSD radix sort of (a,b,c) int32 triples ------------------------------
@@ -1001,31 +903,27 @@ __global__ void tri_copy_gated(const int* __restrict__ src, int* __restrict__ ds
 }  // namespace
 
 struct McState {
-  DevBuf info, vbase, bsum, boff, csum, coff, layer, layer_asc, totals, sort_tmp, sort_hist;
+  DevBuf info, subs, vbase, bsum, boff, csum, coff, layer, layer_asc, totals, act, sort_tmp, sort_hist;
   bool counted = false;
-  bool classify_linear = false;   // development switch (DISN_MC_CLASSIFY=linear): the round-2 kernel, for A/B runs
+  long long walk_cap = 0;   // workgroups of mc_classify_walk the device holds at once (0 = not asked yet)
   const float* sdf = nullptr;
   Dims d{};
   int nz_global = 0;
   unsigned nb = 0;
-  unsigned long long tot[NCNT] = {0, 0, 0, 0, 0};
+  unsigned long long tot[NCNT + 2] = {0, 0, 0, 0, 0, 0, 0};   // the five counters; tiles with edge slots / with owned triangles
 };
 
 void disn_mc_state_free(DisnCtx* ctx) {
   if (!ctx->mc) return;
   McState* m = ctx->mc;
-  DevBuf* all[] = {&m->info, &m->vbase, &m->bsum, &m->boff, &m->csum, &m->coff, &m->layer, &m->layer_asc, &m->totals, &m->sort_tmp, &m->sort_hist};
+  DevBuf* all[] = {&m->info, &m->subs, &m->vbase, &m->bsum, &m->boff, &m->csum, &m->coff, &m->layer, &m->layer_asc, &m->totals, &m->act, &m->sort_tmp, &m->sort_hist};
   for (DevBuf* b : all) disn_release(*b);
   delete m;
   ctx->mc = nullptr;
 }
 
 static McState* mc_state(DisnCtx* ctx) {
-  if (!ctx->mc) {
-    ctx->mc = new McState();
-    const char* e = getenv("DISN_MC_CLASSIFY");
-    ctx->mc->classify_linear = e && !strcmp(e, "linear");
-  }
+  if (!ctx->mc) ctx->mc = new McState();
   return ctx->mc;
 }
 
@@ -1049,43 +947,58 @@ extern "C" int disn_mc_count(DisnCtx* ctx, const float* sdf, const DisnMcGrid* g
   d.nx = g->nx; d.ny = g->ny; d.nz = g->nz;
   d.sxy = (unsigned)g->nx * g->ny;
   d.P = (unsigned)P64;
+  d.pitch = (g->nx + ITEMS - 1) / ITEMS * ITEMS;
+  const uint64_t Q64 = (uint64_t)d.pitch * g->ny * g->nz;   // <= 2 P
+  d.sxyq = (unsigned)d.pitch * g->ny;
+  d.Q = (unsigned)Q64;
   d.own0 = g->own0; d.own1 = g->own1;
   d.z_offset = g->z_offset;
   d.iso = iso;
-  d.dnx = make_fastdiv((unsigned)g->nx);
+  d.dpitch = make_fastdiv((unsigned)d.pitch);
   d.dny = make_fastdiv((unsigned)g->ny);
-  const unsigned nb = (unsigned)((P64 + TILE - 1) / TILE);
-  DISN_TRY(disn_ensure(ctx, m->info, P64 * sizeof(uint16_t)));
-  DISN_TRY(disn_ensure(ctx, m->bsum, (size_t)nb * NCNT * sizeof(unsigned)));
+  const unsigned nb = (unsigned)((Q64 + TILE - 1) / TILE);
+  DISN_TRY(disn_ensure(ctx, m->info, Q64 * sizeof(uint8_t)));
+  DISN_TRY(disn_ensure(ctx, m->subs, Q64 * sizeof(uint16_t)));
+  DISN_TRY(disn_ensure(ctx, m->bsum, ((size_t)nb * NCNT + 2) * sizeof(unsigned)));   // + the two list lengths
   DISN_TRY(disn_ensure(ctx, m->boff, (size_t)nb * 3 * sizeof(unsigned)));
   const unsigned nchunk = (nb + SCAN_CHUNK - 1) / SCAN_CHUNK;
   DISN_TRY(disn_ensure(ctx, m->csum, (size_t)nchunk * NCNT * sizeof(unsigned)));
   DISN_TRY(disn_ensure(ctx, m->coff, (size_t)nchunk * 3 * sizeof(unsigned)));
   DISN_TRY(disn_ensure(ctx, m->layer, (size_t)(g->nz + 1) * sizeof(unsigned)));
   DISN_TRY(disn_ensure(ctx, m->layer_asc, (size_t)(g->nz + 2) * sizeof(unsigned)));
-  DISN_TRY(disn_ensure(ctx, m->totals, NCNT * sizeof(unsigned long long)));
+  DISN_TRY(disn_ensure(ctx, m->totals, (NCNT + 2) * sizeof(unsigned long long)));
+  DISN_TRY(disn_ensure(ctx, m->act, 2 * (size_t)nb * sizeof(unsigned)));
   DISN_HIP(ctx, hipMemsetAsync(m->layer.p, 0, (size_t)(g->nz + 1) * sizeof(unsigned), stream));
-  if (m->classify_linear) {
-    mc_classify<<<(nb + CLS_TILES - 1) / CLS_TILES, BLK, 0, stream>>>(sdf, d, (uint16_t*)m->info.p, (unsigned*)m->bsum.p, nb,
-                                                                      (unsigned*)m->layer.p);
-  } else {
-    // columns of 4 x 4 points walking L planes; L: enough threads to fill the chip, at least 4 planes per walk
-    const int nq = (g->nx + ITEMS - 1) / ITEMS, ng = (g->ny + WROWS - 1) / WROWS;
-    const long long per_chunk = (long long)nq * ng, want_threads = 512 * 1024;
-    long long nc = (want_threads + per_chunk - 1) / per_chunk;
-    int L = (int)((g->nz + nc - 1) / nc);
-    if (L < 4) L = 4;
-    nc = (g->nz + L - 1) / L;
+  DISN_HIP(ctx, hipMemsetAsync(m->bsum.p, 0, ((size_t)nb * NCNT + 2) * sizeof(unsigned), stream));
+  unsigned* actn = (unsigned*)m->bsum.p + (size_t)nb * NCNT;
+  {
+    // columns of 4 x 4 points walking L planes.  Measured (tools/mc_walk_sweep.sh, sdf_res 256 / 512 / 1024): SHORT walks
+    // win -- 4 planes at 1024 (count 1.37 ms against 2.85 ms with 129 planes), 2..4 at 512, 1 at 256.  The columns that
+    // meet the surface do a hundred times the work of the others, and a long walk keeps that work in few waves; the
+    // extra plane a walk reads at its seam ((L+1)/L) costs less than the imbalance.  So: the longest walk <= 4 planes
+    // that still leaves four workgroups for every slot of the device.
+    if (!m->walk_cap) {
+      int per_cu = 0, cus = 0;
+      DISN_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mc_classify_walk, BLK, 0));
+      DISN_HIP(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+      m->walk_cap = (long long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    }
+    const int nq = d.pitch / ITEMS, ng = (g->ny + WROWS - 1) / WROWS;
+    const long long per_chunk = (long long)nq * ng;
+    int L = 4;
+    while (L > 1 && (per_chunk * ((g->nz + L - 1) / L) + BLK - 1) / BLK < 4 * m->walk_cap) --L;
+    if (const char* e = getenv("DISN_MC_WALK_L")) L = atoi(e) >= 1 ? atoi(e) : L;   // development switch: timing sweeps
+    const long long nc = (g->nz + L - 1) / L;
     const long long nthreads = per_chunk * nc;
-    DISN_HIP(ctx, hipMemsetAsync(m->bsum.p, 0, (size_t)nb * NCNT * sizeof(unsigned), stream));
     mc_classify_walk<<<(unsigned)((nthreads + BLK - 1) / BLK), BLK, 0, stream>>>(
-        sdf, d, (uint16_t*)m->info.p, (unsigned*)m->bsum.p, (unsigned*)m->layer.p, nq, ng, L, make_fastdiv((unsigned)nq),
-        make_fastdiv((unsigned)ng), (unsigned)nthreads);
+        sdf, d, (uint8_t*)m->info.p, (uint16_t*)m->subs.p, (unsigned*)m->bsum.p, (unsigned*)m->layer.p, nq, ng, L,
+        make_fastdiv((unsigned)nq), make_fastdiv((unsigned)ng), (unsigned)nthreads);
   }
-  mc_scan_tiles<<<nchunk, BLK, 0, stream>>>((const unsigned*)m->bsum.p, nb, (unsigned*)m->boff.p, (unsigned*)m->csum.p);
+  mc_scan_tiles<<<nchunk, BLK, 0, stream>>>((const unsigned*)m->bsum.p, nb, (unsigned*)m->boff.p, (unsigned*)m->csum.p, actn,
+                                            (unsigned*)m->act.p);
   mc_scan<<<1, 1024, 0, stream>>>((const unsigned*)m->csum.p, nchunk, (unsigned*)m->coff.p,
                                   (unsigned long long*)m->totals.p, (const unsigned*)m->layer.p,
-                                  (unsigned*)m->layer_asc.p, g->nz);
+                                  (unsigned*)m->layer_asc.p, g->nz, actn);
   DISN_HIP(ctx, hipGetLastError());
   DISN_HIP(ctx, hipMemcpyAsync(m->tot, m->totals.p, sizeof(m->tot), hipMemcpyDeviceToHost, stream));
   DISN_HIP(ctx, hipStreamSynchronize(stream));
@@ -1214,7 +1127,7 @@ extern "C" int disn_mc_emit(DisnCtx* ctx, const double* bbox, uint64_t centre_ba
   DISN_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t stream = (hipStream_t)stream_;
   const Dims& d = m->d;
-  DISN_TRY(disn_ensure(ctx, m->vbase, (size_t)d.P * sizeof(unsigned)));
+  DISN_TRY(disn_ensure(ctx, m->vbase, (size_t)d.Q * sizeof(unsigned)));
   EmitArgs a;
   const int ng[3] = {d.nx, d.ny, m->nz_global};
   for (int q = 0; q < 3; ++q) {
@@ -1228,11 +1141,19 @@ extern "C" int disn_mc_emit(DisnCtx* ctx, const double* bbox, uint64_t centre_ba
   a.verts = verts;
   a.keys = (long long*)keys;
   a.tris = tris;
-  mc_vertices<<<m->nb, BLK, 0, stream>>>(m->sdf, d, (const uint16_t*)m->info.p, (const unsigned*)m->bsum.p,
-                                         (const unsigned*)m->boff.p, (const unsigned*)m->coff.p, (unsigned*)m->vbase.p, a);
-  mc_triangles<<<m->nb, BLK, 0, stream>>>(m->sdf, d, (const uint16_t*)m->info.p, (const unsigned*)m->bsum.p,
-                                          (const unsigned*)m->boff.p, (const unsigned*)m->coff.p, (const unsigned*)m->vbase.p,
-                                          (const unsigned*)m->layer_asc.p, a);
+  const unsigned* act = (const unsigned*)m->act.p;
+  const unsigned nvl = (unsigned)m->tot[NCNT], ntl = (unsigned)m->tot[NCNT + 1], wpb = BLK / 64;   // one wave per listed tile
+  if (nvl)
+    mc_vertices<<<(nvl + wpb - 1) / wpb, BLK, 0, stream>>>(m->sdf, d, (const uint8_t*)m->info.p, (const unsigned*)m->boff.p,
+                                                           (const unsigned*)m->coff.p, (unsigned*)m->vbase.p, a, act, nvl);
+  if (ntl) {
+    mc_tri_records<<<(ntl + wpb - 1) / wpb, BLK, 0, stream>>>(d, (const uint8_t*)m->info.p, (const uint16_t*)m->subs.p,
+                                                              (const unsigned*)m->boff.p, (const unsigned*)m->coff.p, tris,
+                                                              act + (size_t)m->nb, ntl);
+    mc_tri_finish<<<(unsigned)((nt + BLK - 1) / BLK), BLK, 0, stream>>>(m->sdf, d, (const uint8_t*)m->info.p,
+                                                                        (const unsigned*)m->vbase.p,
+                                                                        (const unsigned*)m->layer_asc.p, a, (unsigned)nt);
+  }
   DISN_HIP(ctx, hipGetLastError());
   if (sort) DISN_TRY(sort_tris(ctx, m, tris, nt, max_index, stream, false));
   return DISN_OK;
@@ -1244,8 +1165,9 @@ extern "C" int disn_mc_debug_info(DisnCtx* ctx, uint16_t* out, void* stream_) {
   if (!m || !m->counted) return disn_fail(ctx, DISN_E_STATE, "disn_mc_debug_info: call disn_mc_count first");
   if (!out) return disn_fail(ctx, DISN_E_ARG, "disn_mc_debug_info: null output");
   DISN_HIP(ctx, hipSetDevice(ctx->device));
-  DISN_HIP(ctx, hipMemcpyAsync(out, m->info.p, (size_t)m->d.P * sizeof(uint16_t), hipMemcpyDeviceToDevice,
-                               (hipStream_t)stream_));
+  mc_export_info<<<(m->d.Q + BLK - 1) / BLK, BLK, 0, (hipStream_t)stream_>>>(m->d, (const uint8_t*)m->info.p,
+                                                                               (const uint16_t*)m->subs.p, out);
+  DISN_HIP(ctx, hipGetLastError());
   return DISN_OK;
 }
 

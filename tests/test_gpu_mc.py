@@ -185,27 +185,24 @@ def test_tiny_and_skewed_grids(ctx, shape):
     check(ctx, g, iso=0.2, bbox=(-1, -2, -3, 2, 1, 0.5))
 
 
-def test_walking_classifier_equals_linear_classifier(monkeypatch):
-    """mc_classify_walk (columns of 4 x 4 points walking up the planes, surface points queued per wave) against the
-    round-2 linear-tile kernel (DISN_MC_CLASSIFY=linear): identical per-point info (sub-table ids + edge flags),
-    counts and meshes on noise (every voxel mixed), an analytic field, slabs with halo and skewed small grids."""
-    import torch
-    from disn_amd.api import Context
-    monkeypatch.setenv("DISN_MC_CLASSIFY", "linear")
-    lin = Context(0)
-    lin.mc_count(torch.zeros((2, 2, 2), device="cuda"), 1.0)       # creates the MC state while the variable is set
-    monkeypatch.delenv("DISN_MC_CLASSIFY")
-    walk = Context(0)
+def test_classification_matches_oracle_per_point(ctx):
+    """The walking classifier's per-point record (disn_mc_debug_info: sub-table id of the point's voxel and its
+    three edge-slot flags) against the oracle on noise (every voxel mixed), an analytic field, slabs with halo
+    and rows that need padding to the arrays' row pitch (nx = 21, 6, 30, 49, 97: none a multiple of 4)."""
     cases = [(fields.noise_field((9, 13, 21), seed=3), 0.01, {}), (fields.noise_field((37, 5, 6), seed=4), -0.02, {}),
              (fields.analytic_field(48), 0.0, {}),
              (fields.noise_field((23, 17, 30), seed=5), 0.0, dict(z_offset=4, nz_global=40, own=(1, 12))),
              (fields.analytic_field(96)[10:41], 0.0, dict(z_offset=10, nz_global=97, own=(1, 29)))]
     for g, iso, kw in cases:
-        t = torch.from_numpy(np.ascontiguousarray(g)).cuda()
-        ca, cb = lin.mc_count(t, iso, **kw), walk.mc_count(t, iso, **kw)
-        assert ca == cb and ca[2] > 0
-        assert torch.equal(lin.mc_debug_info(), walk.mc_debug_info())
-        (va, ta), (vb, tb) = lin.mc_emit(), walk.mc_emit()
-        assert torch.equal(va, vb) and torch.equal(ta, tb)
-    lin.close()
-    walk.close()
+        g = np.ascontiguousarray(g)
+        counts = ctx.mc_count(torch.from_numpy(g).cuda(), iso, **kw)
+        assert counts[2] > 0
+        info = ctx.mc_debug_info().cpu().numpy().astype(np.uint16)
+        sub = (info & 0x3ff).astype(np.int32)
+        sub[sub == 0x3ff] = -1
+        assert np.array_equal(sub, mc.classify(g, iso).astype(np.int32))
+        ref = mc.marching_cubes(g, iso=iso)
+        want = np.zeros(g.size, np.uint16)
+        ek = ref["keys"][ref["n_centre"]:]
+        np.bitwise_or.at(want, ek // 3, (1 << (ek % 3)).astype(np.uint16))
+        assert np.array_equal((info >> 10).reshape(-1), want)
