@@ -13,7 +13,7 @@ for f in sorted(glob.glob('gpurun_out/pmcmc_*/**/*counter_collection.csv', recur
     acc = {}
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        for n in ('mc_classify', 'mc_vertices', 'mc_triangles'):
+        for n in ('mc_classify_walk', 'mc_vertices', 'mc_tri_records', 'mc_tri_finish'):
             if n in k:
                 acc.setdefault((n, r['Counter_Name']), []).append(float(r['Counter_Value']))
     for (n, c), v in sorted(acc.items()):
