@@ -52,6 +52,8 @@ SIGNATURES = {
     "disn_mc_debug_info": (c_int, [c_void_p, c_void_p, c_void_p]),
     "disn_sort_triangles": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
     "disn_sort_triangles_static": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
+    "disn_df_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "disn_df_flood": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
     "disn_write_dist": (c_int, [c_char_p, c_int, c_void_p, c_void_p]),
     "disn_read_dist_header": (c_int, [c_char_p, ctypes.POINTER(c_int), c_void_p]),
     "disn_read_dist": (c_int, [c_char_p, c_void_p, ctypes.c_size_t]),

@@ -226,6 +226,26 @@ int disn_sort_triangles(DisnCtx* ctx, int32_t* tris, uint64_t n, uint64_t max_in
  * calls that overlap in time on the same GPU (different streams / contexts / threads) race -- serialise them. */
 int disn_sort_triangles_static(DisnCtx* ctx, int32_t* tris, uint64_t n, uint64_t max_index, void* stream);
 
+/* ---- distance field of a triangle mesh (ground-truth generation) ---- */
+/* The device half of the replacement for `computeDistanceField <obj> res res res [-s] [-m mode] [-g sigma]`
+ * (closed Vega-FEM tool; reference call site preprocessing/create_point_sdf_grid.py:200-210, output format
+ * :29-51).  Exact distance from every point of an nx x ny x nz grid spanning bbox (HOST double[6], lo xyz, hi xyz;
+ * point i = lo + i (hi - lo) / (n - 1), x fastest) to the nearest triangle, float64 arithmetic, float32 result.
+ *   geom    : DEVICE double[n_tris][9] = corners a, b, c; no degenerate triangles; for speed, consecutive triangles
+ *             should be close in space (the host side orders them along a Morton curve)
+ *   normals : NULL -> unsigned distance; else DEVICE double[n_tris][7][3] = face normal, pseudonormals of the
+ *             vertices a, b, c and of the edges ab, ac, bc (Baerentzen & Aanaes 2005): the result carries the sign of
+ *             (p - closest point) . pseudonormal of the closest feature -- negative inside a closed manifold surface
+ *             (the tool's `-s -m 0`).  The tool's `-m 1` pipeline (Xu & Barbic 2014) is built from this call,
+ *             disn_df_flood and disn_mc_* by disn_amd/distance_field.py.
+ * Ties between triangles go to the lower index, so the result does not depend on the traversal.  SYNCHRONOUS. */
+int disn_df_eval(DisnCtx* ctx, const double* geom, const double* normals, uint64_t n_tris, int nx, int ny, int nz,
+                 const double* bbox, float* out, void* stream);
+/* exterior[p] = 1 iff grid point p is connected to the boundary of the grid through points with field > level
+ * (6-neighbourhood), else 0: the "remove the interior components of the offset surface" step of the same pipeline.
+ * field: DEVICE float[nx*ny*nz], exterior: DEVICE uint8[nx*ny*nz].  SYNCHRONOUS. */
+int disn_df_flood(DisnCtx* ctx, const float* field, float level, int nx, int ny, int nz, uint8_t* exterior, void* stream);
+
 /* ---- file formats (host) ----------------------------------------------- */
 /* .dist writer/reader.  Replaces to_binary (reference: demo/demo.py:342-353;
  * reader preprocessing/create_point_sdf_grid.py:29-51): int32 -res, res, res;
