@@ -195,6 +195,11 @@ def main(argv=None):
     ap.add_argument("-g", dest="sigma", type=float, default=None)
     ap.add_argument("-G", dest="sigma_grid", type=float, default=None)
     ap.add_argument("--gpu", type=int, default=0)
+    argv = list(sys.argv[1:] if argv is None else argv)
+    for q in range(len(argv) - 1):           # "-b -1,-1,-1,1,1,1": the value starts with a minus sign
+        if argv[q] == "-b":
+            argv[q:q + 2] = ["-b=" + argv[q + 1]]
+            break
     a = ap.parse_args(argv)
     if len(set(a.resolution)) != 1 or a.resolution[0] < 1:
         sys.exit("Invalid resolution.")
