@@ -1,6 +1,6 @@
 // df_point_triangle.h -- closest point of a triangle to a point, float64, one fixed sequence of separately rounded
-// operations (compile with -ffp-contract=off).  Shared by the GPU distance-field kernels (csrc/df.hip) and by nothing
-// else in the product; the CPU oracle (oracle/df_oracle.c) restates the same sequence on its own.
+// operations (compile with -ffp-contract=off).  Used by the GPU distance-field kernels (csrc/df.hip) only; the CPU
+// checker under tests/ measures the same distances with a different formulation.
 //
 // Algorithm: the Voronoi-region walk of Ericson, "Real-Time Collision Detection" (2005) s5.1.5.  region: 0 = face
 // interior, 1 2 3 = vertex a b c, 4 = edge ab, 5 = edge ac, 6 = edge bc.  Returns the squared distance; q = the
