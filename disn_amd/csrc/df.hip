@@ -99,6 +99,7 @@ __global__ __launch_bounds__(DF_BLK) void k_df_eval(const double* __restrict__ g
                                                      unsigned n_tris, const double* __restrict__ spheres, unsigned n_chunks,
                                                      DfGrid g, float* __restrict__ out) {
   __shared__ double sgeom[DF_CHUNK * 9];
+  __shared__ double ssph[DF_CHUNK * 4];   // per triangle of the staged chunk: centroid and radius to its farthest corner
   __shared__ double red[DF_BLK / 64];
   __shared__ unsigned cand[DF_BLK];
   __shared__ unsigned ncand;
@@ -125,22 +126,85 @@ __global__ __launch_bounds__(DF_BLK) void k_df_eval(const double* __restrict__ g
     br2 += e * e;
   }
   const double brad = sqrt(br2) * (1.0 + 1e-12);
-  // phase A: upper bound of any brick point's distance from the spheres alone
-  double ub = DBL_MAX;
-  for (unsigned c = threadIdx.x; c < n_chunks; c += DF_BLK) {
-    const double* s = spheres + (size_t)c * 4;
-    const double d[3] = {s[0] - bc[0], s[1] - bc[1], s[2] - bc[2]};
-    ub = fmin(ub, sqrt(df_dot(d, d)) + s[3]);
-  }
-  ub = (block_reduce(ub, red, false) + brad) * (1.0 + 1e-9);
-  // phase B: exact tests of the chunks that can reach below the bound
-  double best[2] = {DBL_MAX, DBL_MAX};
+  double best[2] = {DBL_MAX, DBL_MAX}, sbest[2] = {DBL_MAX, DBL_MAX};   // squared distance; distance, rounded up
   unsigned bidx[2] = {0xffffffffu, 0xffffffffu};
+  double ub = DBL_MAX;
+  // exact tests of one chunk against this thread's two points, then the brick's new bound: its farthest point
+  auto test_chunk = [&](unsigned ch) {
+    const unsigned t0 = ch * DF_CHUNK;
+    const unsigned nt = min((unsigned)DF_CHUNK, n_tris - t0);
+    __syncthreads();
+    for (unsigned x = threadIdx.x; x < nt * 9; x += DF_BLK) sgeom[x] = geom[(size_t)t0 * 9 + x];
+    __syncthreads();
+    if (threadIdx.x < nt) {
+      const double* tg = sgeom + threadIdx.x * 9;
+      double c[3], r2 = 0.0;
+      for (int a = 0; a < 3; ++a) c[a] = (tg[a] + tg[3 + a] + tg[6 + a]) / 3.0;
+      for (int v = 0; v < 3; ++v) {
+        const double d[3] = {tg[3 * v] - c[0], tg[3 * v + 1] - c[1], tg[3 * v + 2] - c[2]};
+        r2 = fmax(r2, df_dot(d, d));
+      }
+      double* o = ssph + threadIdx.x * 4;
+      o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+      o[3] = sqrt(r2) * (1.0 + 1e-12);
+    }
+    __syncthreads();
+    for (unsigned t = 0; t < nt; ++t) {
+      const double* tg = sgeom + t * 9;
+      const double* sp = ssph + t * 4;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        // a dozen operations decide for most triangles: the whole triangle lies in its sphere, so it is farther
+        // than |p - centre| - radius; strictly farther than the best so far -> it cannot win, not even a tie
+        const double dc[3] = {p[u][0] - sp[0], p[u][1] - sp[1], p[u][2] - sp[2]};
+        const double lim = sbest[u] + sp[3];
+        if (df_dot(dc, dc) > lim * lim) continue;
+        int region;
+        double q[3];
+        const double d2 = df_point_triangle(p[u], tg, tg + 3, tg + 6, &region, q);
+        const unsigned idx = t0 + t;
+        if (d2 < best[u] || (d2 == best[u] && idx < bidx[u])) {
+          best[u] = d2;
+          bidx[u] = idx;
+          sbest[u] = sqrt(d2) * (1.0 + 1e-12);
+        }
+      }
+    }
+    double worst = 0.0;
+    for (int u = 0; u < 2; ++u)
+      if (have[u]) worst = fmax(worst, best[u]);
+    worst = block_reduce(worst, red, true);
+    if (worst < DBL_MAX) ub = fmin(ub, sqrt(worst) * (1.0 + 1e-9));
+  };
+  // phase A: the chunk whose sphere promises the smallest distance to the brick's centre is tested first, so that the
+  // bound is tight before anything else is looked at (in list order the first chunks tested are usually far ones,
+  // and a loose bound lets most of the mesh through: 4 ms per brick on a 26 K-triangle mesh, measured)
+  unsigned first = 0;
+  {
+    double mine = DBL_MAX;
+    unsigned mine_c = 0;
+    for (unsigned c = threadIdx.x; c < n_chunks; c += DF_BLK) {
+      const double* s = spheres + (size_t)c * 4;
+      const double d[3] = {s[0] - bc[0], s[1] - bc[1], s[2] - bc[2]};
+      const double v = sqrt(df_dot(d, d)) + s[3];
+      if (v < mine) { mine = v; mine_c = c; }
+    }
+    const double lowest = block_reduce(mine, red, false);
+    if (threadIdx.x == 0) ncand = 0xffffffffu;
+    __syncthreads();
+    if (mine == lowest) atomicMin(&ncand, mine_c);   // ties: the lowest chunk index, so the choice is deterministic
+    __syncthreads();
+    first = ncand;
+    ub = (lowest + brad) * (1.0 + 1e-9);
+    __syncthreads();
+  }
+  test_chunk(first);
+  // phase B: the other chunks that can still reach below the bound
   for (unsigned c0 = 0; c0 < n_chunks; c0 += DF_BLK) {
     if (threadIdx.x == 0) ncand = 0;
     __syncthreads();
     const unsigned c = c0 + threadIdx.x;
-    if (c < n_chunks) {
+    if (c < n_chunks && c != first) {
       const double* s = spheres + (size_t)c * 4;
       const double d[3] = {s[0] - bc[0], s[1] - bc[1], s[2] - bc[2]};
       const double lb = sqrt(df_dot(d, d)) - s[3] - brad;
@@ -150,35 +214,12 @@ __global__ __launch_bounds__(DF_BLK) void k_df_eval(const double* __restrict__ g
     const unsigned nc = ncand;
     for (unsigned e = 0; e < nc; ++e) {
       const unsigned ch = cand[e];
-      {
-        // has the bound tightened enough to drop this chunk?  (all points of the brick already closer than it can be)
-        const double* s = spheres + (size_t)ch * 4;
-        const double d[3] = {s[0] - bc[0], s[1] - bc[1], s[2] - bc[2]};
-        const double lb = sqrt(df_dot(d, d)) - s[3] - brad;
-        if (lb > 0.0 && lb * lb > ub * ub) continue;   // block-uniform
-      }
-      const unsigned t0 = ch * DF_CHUNK;
-      const unsigned nt = min((unsigned)DF_CHUNK, n_tris - t0);
-      __syncthreads();
-      for (unsigned x = threadIdx.x; x < nt * 9; x += DF_BLK) sgeom[x] = geom[(size_t)t0 * 9 + x];
-      __syncthreads();
-      for (unsigned t = 0; t < nt; ++t) {
-        const double* tg = sgeom + t * 9;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          int region;
-          double q[3];
-          const double d2 = df_point_triangle(p[u], tg, tg + 3, tg + 6, &region, q);
-          const unsigned idx = t0 + t;
-          if (d2 < best[u] || (d2 == best[u] && idx < bidx[u])) { best[u] = d2; bidx[u] = idx; }
-        }
-      }
-      // new bound: the farthest of the brick's points (those that exist)
-      double worst = 0.0;
-      for (int u = 0; u < 2; ++u)
-        if (have[u]) worst = fmax(worst, best[u]);
-      worst = block_reduce(worst, red, true);
-      if (worst < DBL_MAX) ub = fmin(ub, sqrt(worst) * (1.0 + 1e-9));
+      // has the bound tightened enough to drop this chunk?  (every point of the brick already closer than it can be)
+      const double* s = spheres + (size_t)ch * 4;
+      const double d[3] = {s[0] - bc[0], s[1] - bc[1], s[2] - bc[2]};
+      const double lb = sqrt(df_dot(d, d)) - s[3] - brad;
+      if (lb > ub) continue;   // block-uniform
+      test_chunk(ch);
     }
     __syncthreads();
   }
