@@ -324,8 +324,10 @@ extern "C" int disn_df_flood(DisnCtx* ctx, const float* field, float level, int 
   DISN_TRY(disn_ensure(ctx, flag, sizeof(unsigned)));
   const size_t sx = 1, sy = (size_t)nx, sz = (size_t)nx * ny;
   k_flood_init<<<4096, 256, 0, stream>>>(field, level, nx, ny, nz, exterior);
-  int rc = DISN_OK;
-  for (int round = 0; round < 4096; ++round) {
+  // a round carries the flood along whole grid lines, so even a maze needs few rounds; the cap only bounds the loop
+  const int max_rounds = 2 * (nx + ny + nz) + 16;
+  int rc = 1;   // 1 = still flooding
+  for (int round = 0; round < max_rounds; ++round) {
     hipError_t e = hipMemsetAsync(flag.p, 0, sizeof(unsigned), stream);
     if (e == hipSuccess) {
       k_flood_sweep<<<(ny * nz + 255) / 256, 256, 0, stream>>>(field, level, ny * nz, ny, sy, nz, sz, nx, sx, exterior, (unsigned*)flag.p);
@@ -337,8 +339,9 @@ extern "C" int disn_df_flood(DisnCtx* ctx, const float* field, float level, int 
     if (e == hipSuccess) e = hipMemcpyAsync(&changed, flag.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) { rc = disn_fail(ctx, DISN_E_HIP, "disn_df_flood: %s", hipGetErrorString(e)); break; }
-    if (!changed) break;
+    if (!changed) { rc = DISN_OK; break; }
   }
   disn_release(flag);
+  if (rc == 1) rc = disn_fail(ctx, DISN_E_STATE, "disn_df_flood: no fixed point after %d rounds", max_rounds);
   return rc;
 }
