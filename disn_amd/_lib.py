@@ -59,6 +59,7 @@ SIGNATURES = {
     "disn_read_dist": (c_int, [c_char_p, c_void_p, ctypes.c_size_t]),
     "disn_read_ndist_header": (c_int, [c_char_p, ctypes.POINTER(c_int), c_void_p, ctypes.POINTER(c_int64)]),
     "disn_read_ndist": (c_int, [c_char_p, c_void_p, ctypes.c_size_t]),
+    "disn_write_ndist": (c_int, [c_char_p, c_int, c_void_p, c_void_p, c_float]),
     "disn_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, c_void_p, ctypes.c_size_t]),
     "disn_write_obj": (c_int, [c_char_p, c_void_p, c_uint64, c_void_p, c_uint64]),
 }

@@ -299,6 +299,17 @@ def read_narrowband_dist(path):
     return res.value, bb, v.reshape(n1, n1, n1), n.value
 
 
+def write_narrowband_dist(path, res, bbox, values, band):
+    """the cells with |value| < band as a narrow-band .n.dist (the distance-field tool's `-n -w band` output)"""
+    v = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
+    if v.size != (res + 1) ** 3:
+        raise DisnError("write_narrowband_dist: need (res+1)^3 values")
+    bb = np.ascontiguousarray(np.asarray(bbox, dtype=np.float64).reshape(6))
+    rc = _lib.load().disn_write_ndist(path.encode(), res, bb.ctypes.data, v.ctypes.data, ctypes.c_float(band))
+    if rc != 0:
+        raise DisnError("disn_write_ndist(%s) failed (%d)" % (path, rc))
+
+
 def write_obj(path, verts, tris):
     v = np.ascontiguousarray(np.asarray(verts, dtype=np.float64).reshape(-1, 3))
     t = np.ascontiguousarray(np.asarray(tris, dtype=np.int32).reshape(-1, 3))

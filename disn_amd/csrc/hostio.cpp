@@ -49,6 +49,37 @@ extern "C" int disn_read_dist(const char* path, float* values, size_t n_values) 
   return ok ? DISN_OK : DISN_E_IO;
 }
 
+// narrow-band writer (the `-n -w band` output of the distance-field tool): the dense header, int32 N, then the N cells
+// with |value| < band as (int32 i, j, k, float32 d), here in x-fastest order (the tool's own files list them in no
+// particular order; readers must not depend on it)
+extern "C" int disn_write_ndist(const char* path, int res, const double* bbox, const float* values, float band) {
+  if (!path || !bbox || !values || res < 1 || !(band > 0.0f)) return DISN_E_ARG;
+  const int n = res + 1;
+  size_t count = 0;
+  const size_t total = (size_t)n * n * n;
+  for (size_t p = 0; p < total; ++p) count += fabsf(values[p]) < band;
+  if (count > 0x7fffffffull) return DISN_E_ARG;
+  FILE* f = fopen(path, "wb");
+  if (!f) return DISN_E_IO;
+  const int32_t hdr[3] = {-res, res, res}, cnt = (int32_t)count;
+  bool ok = fwrite(hdr, sizeof hdr, 1, f) == 1 && fwrite(bbox, sizeof(double), 6, f) == 6 && fwrite(&cnt, sizeof cnt, 1, f) == 1;
+  struct Cell { int32_t i, j, k; float d; };
+  std::vector<Cell> buf;
+  buf.reserve(1 << 16);
+  for (int k = 0; ok && k < n; ++k)
+    for (int j = 0; j < n; ++j) {
+      const float* row = values + ((size_t)k * n + j) * n;
+      for (int i = 0; i < n; ++i)
+        if (fabsf(row[i]) < band) buf.push_back(Cell{i, j, k, row[i]});
+      if (buf.size() >= (1 << 16) - (size_t)n || (k == n - 1 && j == n - 1)) {
+        ok = ok && (buf.empty() || fwrite(buf.data(), sizeof(Cell), buf.size(), f) == buf.size());
+        buf.clear();
+      }
+    }
+  ok = (fclose(f) == 0) && ok;
+  return ok ? DISN_OK : DISN_E_IO;
+}
+
 extern "C" int disn_read_ndist_header(const char* path, int* res, double* bbox, int64_t* n_cells) {
   if (!path || !res || !bbox || !n_cells) return DISN_E_ARG;
   int rc = disn_read_dist_header(path, res, bbox);

@@ -6,7 +6,7 @@ ground-truth tool
 (closed Vega-FEM binary; call site preprocessing/create_point_sdf_grid.py:200-210, output read back by get_sdf
 :29-51 and meshed by computeMarchingCubes -i 0.003 :248-252).  Flags and their meaning follow the tool's help text:
 -s signed, -m 0 BASIC (closed manifold mesh, pseudonormal sign) / -m 1 POLYGONSOUP, -g sigma / -G sigma in grid
-cells, -e expansion ratio of the automatic box, -c cube box, -b explicit box, -o output.
+cells, -e expansion ratio of the automatic box, -c cube box, -b explicit box, -o output, -n -w/-W narrow-band output.
 
 POLYGONSOUP is the published pipeline the help text names (Xu & Barbic, "Signed Distance Fields for Polygon Soup
 Meshes", Graphics Interface 2014), built here from the library's own pieces, all on the GPU:
@@ -192,6 +192,9 @@ def main(argv=None):
     ap.add_argument("-b", dest="box", default=None, help="xmin,ymin,zmin,xmax,ymax,zmax")
     ap.add_argument("-c", dest="cube", action="store_true")
     ap.add_argument("-e", dest="expand", type=float, default=1.5)
+    ap.add_argument("-n", dest="narrow", action="store_true", help="write only the narrow band |d| < band (.n.dist layout)")
+    ap.add_argument("-w", dest="band", type=float, default=None, help="band width")
+    ap.add_argument("-W", dest="band_grid", type=float, default=None, help="band width in grid sizes")
     ap.add_argument("-g", dest="sigma", type=float, default=None)
     ap.add_argument("-G", dest="sigma_grid", type=float, default=None)
     ap.add_argument("--gpu", type=int, default=0)
@@ -227,7 +230,14 @@ def main(argv=None):
         if sigma is None or not sigma > 0:
             sys.exit("No valid sigma given.")
         field = df.signed_polygon_soup(verts, faces, res, bbox, sigma)
-    api.write_dist(a.out, res, bbox, field.cpu().numpy())
+    if a.narrow:
+        # the whole field is computed and the band cut out of it afterwards (the tool confines the computation to the band)
+        band = a.band if a.band is not None else (a.band_grid * (bbox[3] - bbox[0]) / res if a.band_grid else None)
+        if band is None or not band > 0:
+            sys.exit("Error: No valid band width is provided.")
+        api.write_narrowband_dist(a.out, res, bbox, field.cpu().numpy(), band)
+    else:
+        api.write_dist(a.out, res, bbox, field.cpu().numpy())
     print("Saving the distance field to %s" % a.out)
 
 

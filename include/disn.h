@@ -263,6 +263,9 @@ int disn_read_dist(const char* path, float* values, size_t n_values);
  * HOST pointers. */
 int disn_read_ndist_header(const char* path, int* res, double* bbox, int64_t* n_cells);
 int disn_read_ndist(const char* path, float* values, size_t n_values);
+/* The same format written: the cells of a dense (res+1)^3 grid with |value| < band (the distance-field tool's
+ * `-n -w band` output mode), in x-fastest order.  HOST pointers. */
+int disn_write_ndist(const char* path, int res, const double* bbox, const float* values, float band);
 /* OBJ writer in the reference tool's text format:
  * header comments, `v x y z` with 6 significant digits, `f a b c` 1-based. */
 int disn_write_obj(const char* path, const double* verts, uint64_t n_verts, const int32_t* tris,

@@ -98,3 +98,31 @@ def test_oracle_polygon_soup_pipeline_fills_cavity_and_keeps_open_sheets():
     on_sheet = (np.abs(x - 0.75) < 0.05) & (np.abs(y) < 0.2) & (np.abs(z) < 0.2)
     # an open sheet has no inside: around it the result is the plain distance again (DISN meshes such fields at 0.003)
     assert on_sheet.any() and np.abs(s - U)[on_sheet].max() <= 1e-3
+
+
+def test_narrowband_writer_round_trips_through_the_reader(tmp_path):
+    """disn_write_ndist (the tool's `-n -w band` output) -> disn_read_ndist: listed cells come back bit for bit, the
+    others as +-FLT_MAX on the right side, and the band meshes exactly like the dense field (CPU oracle)."""
+    import struct
+    import fields
+    from disn_amd import api
+    from oracle import mc
+    res = 32
+    g = fields.analytic_field(res)
+    bbox = (-1, -1, -1, 1, 1, 1)
+    h = 2.0 / res
+    p = str(tmp_path / "a.n.dist")
+    api.write_narrowband_dist(p, res, bbox, g, 3 * h)
+    with open(p, "rb") as fh:
+        raw = fh.read()
+    assert struct.unpack("<3i", raw[:12]) == (-res, res, res) and struct.unpack("<6d", raw[12:60]) == tuple(float(b) for b in bbox)
+    n = struct.unpack("<i", raw[60:64])[0]
+    band = np.abs(g) < np.float32(3 * h)
+    assert n == int(band.sum()) and len(raw) == 64 + 16 * n
+    r, bb, back, cells = api.read_narrowband_dist(p)
+    assert r == res and cells == n and np.array_equal(back[band], g[band])
+    assert (np.abs(back[~band]) > 1e30).all() and np.array_equal(np.sign(back[~band]), np.sign(g[~band]))
+    a, b = mc.marching_cubes(g, bbox=bbox), mc.marching_cubes(back, bbox=bbox)
+    assert np.array_equal(a["tris"], b["tris"]) and np.array_equal(a["verts"], b["verts"])
+    with pytest.raises(api.DisnError):
+        api.write_narrowband_dist(p, res, bbox, g, 0.0)
