@@ -226,7 +226,7 @@ __global__ __launch_bounds__(DF_BLK) void k_df_eval(const double* __restrict__ g
   for (int u = 0; u < 2; ++u) {
     if (!have[u]) continue;
     double dist = sqrt(best[u]);
-    if (SIGNED) {
+    if (SIGNED && bidx[u] != 0xffffffffu) {   // no winner (non-finite input): leave the huge unsigned value, read nothing
       const double* tg = geom + (size_t)bidx[u] * 9;
       int region;
       double q[3];

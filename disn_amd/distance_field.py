@@ -76,6 +76,10 @@ def pack_mesh(verts, faces, signed):
     unit normals of the faces around the edge) -- Baerentzen & Aanaes 2005."""
     verts = np.asarray(verts, np.float64)
     faces = np.asarray(faces, np.int64)
+    if not np.isfinite(verts).all():
+        raise ValueError("the mesh has non-finite vertex coordinates")
+    if len(faces) and (faces.min() < 0 or faces.max() >= len(verts)):
+        raise ValueError("face index outside the vertex list")
     a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
     n = np.cross(b - a, c - a)
     nn = np.sqrt((n * n).sum(1))

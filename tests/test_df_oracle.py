@@ -52,6 +52,10 @@ def test_pack_drops_degenerate_triangles_and_rejects_empty():
     assert len(geom) == 12
     with pytest.raises(ValueError):
         dfh.pack_mesh(v, np.array([[0, 0, 1]], np.int32), False)
+    with pytest.raises(ValueError, match="finite"):
+        dfh.pack_mesh(v * np.array([1, np.nan, 1]), f, False)
+    with pytest.raises(ValueError, match="index"):
+        dfh.pack_mesh(v, f + 1, False)
 
 
 def test_manifold_check_box_and_obj_reader(tmp_path):

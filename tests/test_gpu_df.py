@@ -153,6 +153,11 @@ def test_argument_errors(ctx):
     bad = (ctypes.c_double * 6)(-1, -1, -1, 1, -1, 1)
     assert ctx.lib.disn_df_eval(ctx._h, g.data_ptr(), None, 1, 2, 2, 2, bad, out.data_ptr(), None) != 0
     assert b"box" in ctx.lib.disn_last_error(ctx._h)
+    # non-finite corners that reach the library directly: no triangle wins, nothing is read through the missing index
+    nan = torch.full((9,), float("nan"), dtype=torch.float64, device="cuda")
+    nrm = torch.zeros(21, dtype=torch.float64, device="cuda")
+    assert ctx.lib.disn_df_eval(ctx._h, nan.data_ptr(), nrm.data_ptr(), 1, 2, 2, 2, bb, out.data_ptr(), None) == 0
+    assert torch.isinf(out).all()
 
 
 def test_cli_surface_writes_the_tools_file_format(dfield, tmp_path):
