@@ -206,3 +206,29 @@ def test_classification_matches_oracle_per_point(ctx):
         ek = ref["keys"][ref["n_centre"]:]
         np.bitwise_or.at(want, ek // 3, (1 << (ek % 3)).astype(np.uint16))
         assert np.array_equal((info >> 10).reshape(-1), want)
+
+
+def test_tool_command_line(tmp_path):
+    """`computeMarchingCubes <dist> <obj> [-i iso] [-n narrowband]` (demo/demo.py:365-369) as
+    `python -m disn_amd.marching_cubes`: the dense .dist of the analytic field and the reference's own narrow-band file
+    through files only; mesh sizes = the tool's, OBJ text = the oracle's mesh in the tool's format."""
+    from disn_amd import api, marching_cubes as cli
+    from test_mc_oracle import _narrowband_file
+    g = fields.analytic_field(64)
+    dist, obj = str(tmp_path / "result.dist"), str(tmp_path / "result.obj")
+    api.write_dist(dist, 64, (-1, -1, -1, 1, 1, 1), g)
+    cli.main([dist, obj, "-i", "0.0"])
+    lines = open(obj).read().splitlines()
+    assert lines[0].startswith("#") and "Number of vertices: 8978" in lines[1] and "Number of faces: 17940" in lines[2]
+    ref = mc.marching_cubes(g)
+    want = str(tmp_path / "want.obj")
+    api.write_obj(want, ref["verts"], ref["tris"])
+    assert open(obj, "rb").read() == open(want, "rb").read()
+    cli.main([dist, obj, "-i", "0.05"])
+    assert "Number of vertices: %d" % len(mc.marching_cubes(g, iso=0.05)["verts"]) in open(obj).read(200)
+    p, _ = _narrowband_file(tmp_path)
+    cli.main([p, obj, "-n", "1"])
+    head = open(obj).read(200)
+    assert "Number of vertices: 3800" in head and "Number of faces: 7604" in head
+    with pytest.raises(SystemExit):
+        cli.main([str(tmp_path / "missing.dist"), obj])
