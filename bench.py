@@ -141,14 +141,38 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
-    if os.environ.get("DISN_DIST_BACKEND", "nccl") != "nccl":
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    comm = None
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)   # identity on a node with one GPU per rank
     torch.cuda.set_device(local_rank)
     if world > 1:
+        import datetime
         import torch.distributed as dist
         backend = os.environ.get("DISN_DIST_BACKEND", "nccl")   # "gloo" only to rehearse N ranks on one GPU
+        comm = backend
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            # RCCL over xGMI.  If the communicator cannot be built or its first collective fails (every rank sees the
+            # same failure: IPC mode, several ranks on one GPU), fall back to gloo with host staging rather than
+            # report nothing -- the line then says so in config.comm.
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=180))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError("all_reduce probe returned %r" % probe.item())
+                comm = "rccl"
+            except Exception as e:   # noqa: BLE001
+                print("bench.py rank %d: RCCL unavailable (%s: %s); falling back to gloo with host staging"
+                      % (rank, type(e).__name__, str(e).splitlines()[0][:200]), file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:   # noqa: BLE001
+                    pass
+                port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+                dist.init_process_group("gloo", init_method="tcp://%s:%d" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), port),
+                                        rank=rank, world_size=world)
+                comm = "gloo (fallback: RCCL unavailable)"
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
@@ -224,7 +248,7 @@ def main():
                                    "OBJ text excluded (other_kernels.mesh_output)" % (res, world),
                        "sdf_res": res, "decoder": decoder, "decoder_selection": args.decoder, "points": points, "mesh_vertices": int(verts.shape[0]),
                        "mesh_triangles": int(tris.shape[0]), "iso": iso,
-                       "per_gpu_points_evaluated": local_pts, "halo": pipe.halo if world > 1 else None,
+                       "per_gpu_points_evaluated": local_pts, "halo": pipe.halo if world > 1 else None, "comm": comm,
                        "stitch": pipe.last_stitch},
             "roofline": {"bound": "mfma", "kernel": "sdf_decode" if decoder == "bf16x3" else "sdf_decode_mx", "achieved": alg_tflops, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": alg_tflops / PEAK_BF16_TFLOPS, "traffic": None,

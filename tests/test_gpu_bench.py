@@ -60,3 +60,4 @@ def test_bench_eight_ranks(res):
     assert d["config"]["mesh_triangles"] > 0 and d["scaling"] == "weak" and d["config"]["stitch"] == "placed"
     if res == 40:
         assert d["config"]["per_gpu_points_evaluated"] == 5 * 41 * 41          # rank 0: exactly its own five planes
+
